@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (where /root/reference
+exists); never on the GPU box.  No reference source is copied: the reference is
+imported as a library with harness-side ``sys.modules`` shims for packages that
+are absent and off the hot path (recipe: SURVEY.md Appendix A), executed on
+seeded synthetic inputs, and only inputs / weights / outputs are written out as
+small ``.npz`` fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Fixture index:
+  g01_haar1d        HaarTransform1D fwd / rev                (INN_utils.py:126-174)
+  g02_haar2d_*      HaarDownsampling fwd / rev, 4 option sets (reshapes.py:191-318)
+  g03_perms         permutation tables + axes per step/block  (networks.py:336-357)
+  g04_<block>_<cl>  coupling blocks fwd / rev                 (coupling_layers.py)
+  g05_ai1*          AllInOneBlock fwd / rev                   (all_in_one_block.py)
+  g06_actnorm       ActNorm data init + fwd / rev             (invertible_resnet.py:11-85)
+  g07_subnet*       wavelet_flow_subnetwork2D(_first)         (networks.py:586-706)
+  g08_omega         cond_network / ResidualBlock (eval)       (networks.py:165-242)
+  g09_step_<bt>_k<k> one full GraphINN step per block type    (networks.py:264-368)
+  g10_pipeline      2-step inverse pipeline + evaluate_INN_forward (CWFA.py:134-196,865-924)
+  g11_unet_*, g11_convnext, g11_attention, g11_lrnn_small, g11_lrnn_full
+"""
+import os
+import sys
+import types
+import argparse
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings("ignore")
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    m = types.ModuleType("numpy.lib.arraysetops")
+    m.isin = np.isin
+    sys.modules["numpy.lib.arraysetops"] = m
+    for name in ["tifffile", "multipagetiff", "torchvision", "lion_pytorch",
+                 "torch.utils.tensorboard"]:
+        mod = types.ModuleType(name)
+        mod.imsave = mod.imread = None
+        mod.Lion = object
+        mod.SummaryWriter = object
+        sys.modules[name] = mod
+    import torch  # noqa
+    import FrEIA.framework as Ff
+    import FrEIA.modules as Fm
+    import INN_utils
+    import networks
+    import unet
+    import CWFA
+    return Ff, Fm, INN_utils, networks, unet, CWFA
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def sd_arrays(module, prefix="sd/"):
+    return {prefix + k: npy(v) for k, v in module.state_dict().items()}
+
+
+def dump(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name:32s} {os.path.getsize(path)/1024:8.1f} KiB  ({len(arrs)} arrays)")
+
+
+def main():
+    import torch
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    torch.set_num_threads(8)
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(1234)
+
+    def rn(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g) * scale
+
+    # ---------------------------------------------------------------- G1
+    x = rn(2, 8, 6, 10)
+    mod = INN_utils.HaarTransform1D([(8, 6, 10)], order_by_wavelet=True)
+    (yf,), jf = mod((x,), rev=False)
+    (yr,), jr = mod((x,), rev=True)
+    dump("g01_haar1d", x=npy(x), y_fwd=npy(yf), y_rev=npy(yr),
+         jac_fwd=np.float64(jf), jac_rev=np.float64(jr))
+
+    # ---------------------------------------------------------------- G2
+    for obw in (False, True):
+        for reb in (1.0, 0.5):
+            x = rn(2, 3, 8, 12)
+            mod = Fm.HaarDownsampling([(3, 8, 12)], order_by_wavelet=obw, rebalance=reb)
+            (yf,), jf = mod((x.clone(),), rev=False)
+            z = rn(2, 12, 4, 6)
+            (xr,), jr = mod((z.clone(),), rev=True)
+            dump(f"g02_haar2d_obw{int(obw)}_reb{reb}", x=npy(x), y_fwd=npy(yf), z=npy(z),
+                 x_rev=npy(xr), jac_fwd=np.float64(jf), jac_rev=np.float64(jr),
+                 order_by_wavelet=np.int64(obw), rebalance=np.float64(reb))
+
+    # ---------------------------------------------------------------- G3 / G9
+    # Steps built exactly as run_CWFA does (CWFA.py:498-510), tiny channel counts.
+    S = 3
+    D, H, W = 16, 12, 16
+    n_ch, cond_ch = 8, 4
+    perms = {}
+    for bt in ["CAT", "GLOW", "RNVP", "GIN", "AI1"]:
+        for ix in range(S - 1):
+            torch.manual_seed(100 + ix)
+            np.random.seed(7)
+            Cn = D // 2 ** (ix + 1)
+            cond_net, inns = networks.conditional_wavelet_flow(
+                [D, H, W], [1, 29, H, W], networks.wavelet_flow_subnetwork2D,
+                lambda: networks.cond_network(29, Cn, ix + 1, S, [], cond_ch),
+                n_internal_ch=n_ch, n_down_steps=ix + 1, use_permutations=True,
+                block_type=bt, n_blocks=4)
+            inn = inns[ix].eval()
+            Dn = D // 2 ** ix
+            # perturb biases / the near-zero `_first` last conv so every path is exercised
+            for p in inn.parameters():
+                if p.requires_grad and p.dtype == torch.float32:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            meta = {}
+            for i, mdl in enumerate(inn.module_list):
+                cls = type(mdl).__name__
+                meta[f"meta/module_{i}"] = np.array(cls)
+                if cls == "PermuteDim":
+                    meta[f"meta/axis_{i}"] = np.int64(mdl.dims_to_permute[1])
+                    perms[f"{bt}/k{ix}/m{i}/axis"] = np.int64(mdl.dims_to_permute[1])
+                if hasattr(mdl, "perm") and mdl.perm is not None and cls != "HaarDownsampling":
+                    perms[f"{bt}/k{ix}/m{i}/perm"] = npy(mdl.perm)
+                if cls == "AllInOneBlock":
+                    perms[f"{bt}/k{ix}/m{i}/w_perm"] = npy(mdl.w_perm)[:, :, 0, 0]
+            meta["meta/node_names"] = np.array([n.name for n in inn.node_list])
+            meta["meta/cond_node_names"] = np.array([n.name for n in inn.condition_nodes])
+            meta["meta/out_node_names"] = np.array([n.name for n in inn.out_nodes])
+            meta["meta/dims_c"] = np.array(inn.dims_c)
+            meta["meta/global_out_shapes"] = np.array(inn.global_out_shapes)
+            x = rn(2, Dn, H, W)
+            c = [rn(2, Cn, H, W), rn(2, Cn, H, W, scale=0.3)]   # [Omega -> 'Condition I', mean detail -> 'Condition']
+            (z, low), jf = inn(x, c=c)
+            xr, jr = inn([z, low], c=c, rev=True)
+            x0, j0 = inn([torch.zeros_like(z), low], c=c, rev=True)
+            dump(f"g09_step_{bt}_k{ix}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z=npy(z), low=npy(low),
+                 jac_fwd=npy(jf), x_rev=npy(xr), jac_rev=npy(jr), x_rev_z0=npy(x0), jac_rev_z0=npy(j0),
+                 D=np.int64(D), H=np.int64(H), W=np.int64(W), ix=np.int64(ix), S=np.int64(S),
+                 n_ch=np.int64(n_ch), cond_ch=np.int64(cond_ch), **meta, **sd_arrays(inn))
+    dump("g03_perms", **perms)
+
+    # ---------------------------------------------------------------- G4
+    networks.networks_n_chans = 8
+    C, Hc, Wc, Cc = 6, 8, 10, 5
+    blocks = {
+        "CAT": Fm.ConditionalAffineTransform, "GLOW": Fm.GLOWCouplingBlock, "RNVP": Fm.RNVPCouplingBlock,
+        "GIN": Fm.GINCouplingBlock, "NICE": Fm.NICECouplingBlock, "ONESIDED": Fm.AffineCouplingOneSided,
+    }
+    for bname, cls in blocks.items():
+        clamps = ["ATAN", "TANH", "SIGMOID"] if bname in ("CAT", "GLOW") else ["ATAN"]
+        for cl in clamps:
+            torch.manual_seed(5)
+            kw = {"subnet_constructor": networks.wavelet_flow_subnetwork2D}
+            if bname != "NICE":
+                kw.update(clamp=1.5, clamp_activation=cl)
+            blk = cls([(C, Hc, Wc)], dims_c=[(Cc, Hc, Wc)], **kw).eval()
+            for p in blk.parameters():
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            x = rn(2, C, Hc, Wc)
+            c = rn(2, Cc, Hc, Wc)
+            (yf,), jf = blk((x,), c=(c,), rev=False)
+            (yr,), jr = blk((x,), c=(c,), rev=True)
+            jf = jf if torch.is_tensor(jf) else torch.full((2,), float(jf))
+            jr = jr if torch.is_tensor(jr) else torch.full((2,), float(jr))
+            dump(f"g04_{bname}_{cl}", x=npy(x), c=npy(c), y_fwd=npy(yf), jac_fwd=npy(jf), y_rev=npy(yr),
+                 jac_rev=npy(jr), clamp=np.float64(1.5), **sd_arrays(blk))
+
+    # ---------------------------------------------------------------- G5
+    for gin in (False, True):
+        for cond in (True, False):
+            torch.manual_seed(6)
+            np.random.seed(11)
+            C = 7
+            blk = Fm.AllInOneBlock([(C, Hc, Wc)], dims_c=[(Cc, Hc, Wc)] if cond else [],
+                                   subnet_constructor=networks.wavelet_flow_subnetwork2D, gin_block=gin).eval()
+            for n_, p in blk.named_parameters():
+                if p.requires_grad:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.2)
+            x = rn(2, C, Hc, Wc)
+            c = (rn(2, Cc, Hc, Wc),) if cond else ()
+            (yf,), jf = blk((x,), c=c, rev=False)
+            (yr,), jr = blk((x,), c=c, rev=True)
+            dump(f"g05_ai1_gin{int(gin)}_cond{int(cond)}", x=npy(x), c=npy(c[0]) if cond else np.zeros(0, np.float32),
+                 y_fwd=npy(yf), jac_fwd=npy(jf), y_rev=npy(yr), jac_rev=npy(jr), **sd_arrays(blk))
+
+    # ---------------------------------------------------------------- G6
+    x = rn(3, 5, 6, 8) * 2.5 + 0.7
+    an = Fm.ActNorm([(5, 6, 8)])
+    (yf,), jf = an((x,), rev=False)        # triggers data-dependent init
+    z = rn(3, 5, 6, 8)
+    (yr,), jr = an((z,), rev=True)
+    dump("g06_actnorm", x=npy(x), y_fwd=npy(yf), jac_fwd=npy(jf), z=npy(z), x_rev=npy(yr), jac_rev=npy(jr),
+         **sd_arrays(an))
+
+    # ---------------------------------------------------------------- G7
+    for first in (False, True):
+        for nch in (8, 64):
+            networks.networks_n_chans = nch
+            torch.manual_seed(8)
+            ci, co = (12, 12) if first else (9, 10)
+            ctor = networks.wavelet_flow_subnetwork2D_first if first else networks.wavelet_flow_subnetwork2D
+            net = ctor(ci, co).eval()
+            for p in net.parameters():
+                p.add_(torch.randn(p.shape, generator=g) * 0.03)
+            x = rn(2, ci, 9, 11)
+            y = net(x)
+            dump(f"g07_subnet_first{int(first)}_ch{nch}", x=npy(x), y=npy(y), c_in=np.int64(ci), c_out=np.int64(co),
+                 n_ch=np.int64(nch), **sd_arrays(net))
+    networks.networks_n_chans = 8
+
+    # ---------------------------------------------------------------- G8
+    for cout, chans3d in ((6, 4), (8, 32)):
+        torch.manual_seed(9)
+        net = networks.cond_network(29, cout, 1, 5, [], chans3d).eval()
+        with torch.no_grad():
+            net.subnetworks[0].relu.weight.fill_(0.2)      # shared PReLU (networks.py:209)
+        x = rn(2, 29, 10, 12)
+        y = net(x)[-1]
+        dump(f"g08_omega_c{cout}_k{chans3d}", x=npy(x), y=npy(y), c_out=np.int64(cout), chans3d=np.int64(chans3d),
+             **sd_arrays(net))
+
+    # ---------------------------------------------------------------- G10
+    S, D, H, W = 3, 16, 16, 16
+    args = argparse.Namespace(INN_max_down_steps=S, force_all_steps_NF=0, n_depths=D, volume_side_size=H)
+    conv_inn, cond_nets = [], []
+    torch.manual_seed(21)
+    np.random.seed(3)
+    for ix in range(S - 1):
+        Cn = D // 2 ** (ix + 1)
+        cn, inns = networks.conditional_wavelet_flow(
+            [D, H, W], [1, 29, H, W], networks.wavelet_flow_subnetwork2D,
+            lambda: networks.cond_network(29, Cn, ix + 1, S, [], 4),
+            n_internal_ch=8, n_down_steps=ix + 1, use_permutations=True, block_type="CAT", n_blocks=4)
+        for p in inns[ix].parameters():
+            if p.requires_grad:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        conv_inn.append(inns[ix].eval())
+        cond_nets.append(cn.eval())
+    B = 2
+    gt = rn(B, D, H, W) + 0.1 * torch.arange(D).view(1, D, 1, 1)   # no empty depths
+    views = rn(B, 29, H, W)
+    stats = (torch.tensor(0.1), torch.tensor(1.3), None, None, torch.tensor(0.0), torch.tensor(1.0))
+    losses, gt_cache, prior, logj = CWFA.evaluate_INN_forward(conv_inn, cond_nets, args, [args] * S, gt.clone(),
+                                                              views, stats)
+    cond_input = (views - stats[0]) / stats[1]
+    mean_cache = [rn(B, D // 2 ** (n + 1), H, W, scale=0.1) for n in range(S - 1)]
+    low = gt_cache[S - 1].clone()
+    up = low
+    ups = {}
+    for n in range(S - 2, -1, -1):
+        cp = [cond_nets[n](cond_input)[-1].float(), mean_cache[n]]
+        z = CWFA.sample_z_truncated((B,) + tuple(conv_inn[n].global_out_shapes[0]), temperature=0)
+        up, lj = conv_inn[n]([z, up], c=cp, rev=True)
+        ups[f"up_{n}"] = npy(up)
+        ups[f"omega_{n}"] = npy(cp[0])
+    fx = dict(gt=npy(gt), views=npy(views), mean_imgs=np.float32(0.1), std_imgs=np.float32(1.3), low=npy(low),
+              losses=np.array([float(l) for l in losses]), prior=np.array([float(l) for l in prior]),
+              logjac=np.array([float(l) for l in logj]), S=np.int64(S), **ups)
+    for n in range(S):
+        fx[f"gt_cache_{n}"] = npy(gt_cache[n])
+    for n in range(S - 1):
+        fx[f"mean_cache_{n}"] = npy(mean_cache[n])
+        fx.update(sd_arrays(conv_inn[n], f"inn{n}/"))
+        fx.update(sd_arrays(cond_nets[n], f"omega{n}/"))
+    dump("g10_pipeline", **fx)
+
+    # ---------------------------------------------------------------- G11
+    for bias in (False, True):
+        torch.manual_seed(31)
+        u = unet.UNet(5, 4, depth=3, wf=3, drop_out=0, use_bias=bias, skip_conn=True, up_mode="upconv",
+                      batch_norm=True)
+        for m_ in u.modules():
+            if isinstance(m_, torch.nn.BatchNorm2d):
+                m_.running_mean.copy_(torch.randn(m_.running_mean.shape, generator=g) * 0.1)
+                m_.running_var.copy_(torch.rand(m_.running_var.shape, generator=g) + 0.5)
+                m_.weight.copy_(torch.rand(m_.weight.shape, generator=g) + 0.5)
+                m_.bias.copy_(torch.randn(m_.bias.shape, generator=g) * 0.1)
+        x = rn(2, 5, 16, 16)
+        sd0 = sd_arrays(u)
+        u.eval()
+        y_eval = u(x)
+        u.train()
+        y_train = u(x)                       # batch statistics (B=2), running stats get updated
+        y_train_b1 = u(x[:1])                # B=1: instance statistics
+        dump(f"g11_unet_bias{int(bias)}", x=npy(x), y_eval=npy(y_eval), y_train=npy(y_train), y_train_b1=npy(y_train_b1),
+             **sd0)
+
+    torch.manual_seed(32)
+    cnx = networks.ConvNeXt(6, 10, drop_prob=0.05, size=16).eval()
+    cnx.m[1].weight.add_(torch.randn(cnx.m[1].weight.shape, generator=g) * 0.1)
+    cnx.m[1].bias.add_(torch.randn(cnx.m[1].bias.shape, generator=g) * 0.1)
+    x = rn(2, 6, 16, 16)
+    dump("g11_convnext", x=npy(x), y=npy(cnx(x)), **sd_arrays(cnx))
+
+    torch.manual_seed(33)
+    att = networks.GlobalAttention(6).eval()
+    x = rn(2, 6, 8, 12)
+    dump("g11_attention", x=npy(x), y=npy(att(x)), **sd_arrays(att))
+
+    # LRNN: weights are NOT shipped (63.7 M params).  The fixture pins (a) the construction-time RNG stream through
+    # per-tensor checksums of the default-initialised state_dict under torch.manual_seed(41), (b) outputs for seeded
+    # inputs that the test regenerates with the same torch CPU generator.
+    torch.manual_seed(41)
+    enc = networks.Encoder(29, 6, 5, 64, True)
+    sums = {}
+    for k, v in enc.state_dict().items():
+        vf = v.double()
+        sums["chk/" + k] = np.array([vf.sum().item(), vf.abs().sum().item(), float(v.numel())])
+    gi = torch.Generator().manual_seed(4242)
+    x_small = torch.randn(2, 29, 16, 16, generator=gi)
+    enc.eval()
+    y_small_eval = enc(x_small)[-1]
+    dump("g11_lrnn_small", y_eval=npy(y_small_eval), seed_init=np.int64(41), seed_input=np.int64(4242), **sums)
+    # full-size (512x512) with the mean-volume branch, eval mode (running BN stats, no drop_path), B=1.
+    # (UNet dropout2d p=0.005 is always active in the reference, unet.py:80,86 -> patched to 0 for determinism.)
+    enc.net.deconv[1].drop_out = 0
+    gi = torch.Generator().manual_seed(4343)
+    x_full = torch.randn(1, 29, 512, 512, generator=gi)
+    mean_full = torch.randn(1, 6, 512, 512, generator=gi) * 0.1
+    # give the LayerNorm affine a non-trivial value (deterministic, regenerated in the test)
+    gl = torch.Generator().manual_seed(4444)
+    for cn_ in enc.net.conv3d:
+        cn_.m[1].weight.copy_(1 + 0.1 * torch.randn(cn_.m[1].weight.shape, generator=gl))
+        cn_.m[1].bias.copy_(0.1 * torch.randn(cn_.m[1].bias.shape, generator=gl))
+    y_full = enc(x_full, mean_full)[-1]
+    y_nomean = enc(x_full)[-1]
+    dump("g11_lrnn_full", y_sub=npy(y_full[:, :, ::23, ::29]), y_nomean_sub=npy(y_nomean[:, :, ::23, ::29]),
+         y_sum=np.float64(y_full.double().sum()), y_abs=np.float64(y_full.double().abs().sum()),
+         seed_init=np.int64(41), seed_input=np.int64(4343), seed_ln=np.int64(4444))
+
+
+if __name__ == "__main__":
+    main()
