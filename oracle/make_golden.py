@@ -59,7 +59,7 @@ def import_reference():
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 def sd_arrays(module, prefix="sd/"):
