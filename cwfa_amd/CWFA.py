@@ -1,0 +1,181 @@
+"""Hot-path drivers (reference: CWFA.py): z sampling (:47-64), the forward pyramid + NLL evaluation
+(``evaluate_INN_forward`` :134-196), the per-volume inverse loop (:865-924) and the training-time NLL (:966-978),
+plus the batch-sharded multi-GPU NLL (new; the reference is single-device).
+
+Out of scope: experiment management of ``run_CWFA`` -- checkpoint discovery, optimisers,
+TensorBoard, metrics, figures, TIFF export.
+"""
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+__all__ = ["sample_z_truncated", "check_empty_depths", "evaluate_INN_forward", "inverse_pass", "nll_step",
+           "nll_terms", "allreduce_nll", "build_networks"]
+
+
+def _no_grad_trunc_normal_(tensor, mean=0., std=1., a=-1., b=1.):
+    """Truncated normal by inverse-CDF sampling (utils.py:42-82 semantics).  Only reached for temperature != 0, a path
+    that raises NameError in the reference itself; provided for completeness and checked
+    statistically only."""
+    def norm_cdf(v):
+        return (1. + math.erf(v / math.sqrt(2.))) / 2.
+    with torch.no_grad():
+        lo, up = norm_cdf((a - mean) / std), norm_cdf((b - mean) / std)
+        tensor.uniform_(2 * lo - 1, 2 * up - 1)
+        tensor.erfinv_()
+        tensor.mul_(std * math.sqrt(2.))
+        tensor.add_(mean)
+        tensor.clamp_(min=a, max=b)
+        return tensor
+
+
+def sample_z_truncated(x, device="cpu", temperature=1):
+    """Latent sample; ``temperature == 0`` (the default of main.py:109) returns zeros.  CWFA.py:47-64.
+    The fused inverse treats ``None`` as an all-zero z and never reads it (``inverse_pass`` does that itself)."""
+    shape_like = torch.is_tensor(x)
+    if temperature == 0:
+        return torch.zeros_like(x, device=device) if shape_like else torch.zeros(x, device=device)
+    base = torch.zeros_like(x, device=device) if shape_like else torch.zeros(x, device=device)
+    return _no_grad_trunc_normal_(base, a=-temperature, b=temperature)
+
+
+def check_empty_depths(gt_volume):
+    """Add tiny noise to depth columns that are constant over depth (avoids degenerate statistics).  CWFA.py:84-96.
+    Bookkeeping on the input volume (torch ops), not part of the kernel path."""
+    empty = gt_volume.std(dim=1) == 0
+    n_depths = gt_volume.shape[1]
+    empty = empty.view(gt_volume.shape[0], empty.shape[0] // gt_volume.shape[0], empty.shape[1], empty.shape[2])
+    if empty.any():
+        sel = empty.repeat(1, n_depths, 1, 1)
+        gt_volume[sel] += torch.normal(0, 0.001, gt_volume[sel].size(), device=gt_volume.device)
+    return gt_volume
+
+
+def nll_terms(graph, x, c):
+    """Forward one step and return the shard-local NLL sums: (Z tuple, logdet[B], sum ||Z0||^2 as float64[1] tensor).
+    The sum of squares comes out of the fused chain kernel (no extra pass over Z)."""
+    sumsq = torch.zeros(1, dtype=torch.float64, device=x.device)
+    Z, logdet = graph(x, c=c, sumsq=sumsq) if getattr(graph, "_plan", None) is not None else graph(x, c=c)
+    if getattr(graph, "_plan", None) is None:
+        st = ops.sample_stats(Z[0].reshape(1, -1, 1, 1))
+        sumsq = st[1:2]
+    return Z, logdet, sumsq
+
+
+def evaluate_INN_forward(conv_inn, cond_nets, args_general, args_nets, gt_volume, input_views, train_statistics,
+                         extra_cond_in=None):
+    """Forward pyramid with per-step likelihood terms.  CWFA.py:134-196.
+    Returns (losses, gt_cache, prior_errors, log_jacobians) with the reference's normalisations."""
+    device = gt_volume.device
+    gt_volume = check_empty_depths(gt_volume)
+    mean_imgs, std_imgs = train_statistics[0], train_statistics[1]
+    losses, prior_errors, log_jacobians = [], [], []
+    gt_cache = args_general.INN_max_down_steps * [None]
+    gt_cache[0] = gt_volume
+    cond_input = (input_views - mean_imgs) / std_imgs
+    B = gt_volume.shape[0]
+    for n_net in range(len(conv_inn)):
+        g = conv_inn[n_net]
+        is_last_step = n_net == args_general.INN_max_down_steps - 1
+        if is_last_step:
+            cond_in = [] if args_general.force_all_steps_NF else [cond_nets[n_net](cond_input)[-1]]
+        else:
+            cond_in = [torch.zeros((B,) + tuple(g.dims_c[0]), device=device)] if len(g.dims_c) > 0 else []
+        if len(g.dims_c) > 1:
+            if extra_cond_in is None:
+                cond_in.append(torch.zeros((B,) + tuple(g.dims_c[1]), device=device))
+            else:
+                cond_in.append(extra_cond_in[n_net].clone())
+        Z, log_jac_det, sumsq = nll_terms(g, gt_volume, cond_in)
+        error_on_prior = sumsq[0].to(torch.float32)
+        numel = Z[-1].numel()
+        curr = (0.5 * error_on_prior - log_jac_det) / numel
+        losses.append(curr.mean())
+        prior_errors.append(0.5 * error_on_prior.mean() / numel)
+        log_jacobians.append(log_jac_det.mean() / numel)
+        if not is_last_step:
+            gt_volume = Z[1]
+            gt_cache[n_net + 1] = gt_volume
+    return losses, gt_cache, prior_errors, log_jacobians
+
+
+def inverse_pass(conv_inn, cond_nets, cond_input, mean_vols_cache, low=None, temperature=0.0, n_samples=1,
+                 keep_all=False):
+    """The reconstruction loop for one batch of views.  CWFA.py:865-924.
+
+    ``cond_nets`` has one condition net per flow step plus, if ``low`` is None, the LRNN encoder as its last entry
+    (CWFA.py:495-496,882).  ``mean_vols_cache[n]`` is the mean-volume detail at step n (CWFA.py:655,899).
+    Returns the full-resolution volume (or every level, coarse -> fine, with ``keep_all``)."""
+    S1 = len(conv_inn)
+    if low is None:
+        up = cond_nets[S1](cond_input, mean_vols_cache[S1 - 1])[-1]
+    else:
+        up = low
+    vols = [up]
+    for n in range(S1 - 1, -1, -1):
+        g = conv_inn[n]
+        cond_processed = [cond_nets[n](cond_input)[-1], mean_vols_cache[n]]
+        if n_samples > 1:
+            cond_processed = [cc.repeat(n_samples, 1, 1, 1) for cc in cond_processed]
+            up = up.repeat(n_samples, 1, 1, 1)
+        if temperature == 0 and getattr(g, "_plan", None) is not None:
+            z = None                              # z == 0: the fused chain never reads it (CWFA.py:54-55)
+        else:
+            z = sample_z_truncated((up.shape[0],) + tuple(g.global_out_shapes[0]), device=up.device,
+                                   temperature=temperature)
+        up, _ = g([z, up], c=cond_processed, rev=True)
+        if n_samples > 1:                         # CWFA.py:913-914: average the samples
+            parts = up.view(n_samples, -1, *up.shape[1:])
+            acc = ops.axpby(parts[0], 1.0 / n_samples)
+            for i in range(1, n_samples):
+                acc = ops.axpby(parts[i], 1.0 / n_samples, acc, 1.0)
+            up = acc
+        vols.append(up)
+    return vols if keep_all else up
+
+
+def nll_step(graph, x, c, group=None):
+    """Training-time NLL of one step, CWFA.py:966-978:  (0.5*||Z0||^2 - mean_b logdet) / numel(batch volume),
+    with the norm taken over the WHOLE (global) batch.  With a process group the three shard sums are all-reduced
+    (RCCL over xGMI on MI355X: one float64[3] message) and every rank returns the identical global value."""
+    Z, logdet, sumsq = nll_terms(graph, x, c)
+    terms = torch.stack([sumsq[0], logdet.to(torch.float64).sum(),
+                         torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)])
+    terms = allreduce_nll(terms, group)
+    numel_total = terms[2] * (Z[1][0].numel() if len(Z) > 1 else Z[0][0].numel())
+    nll = (0.5 * terms[0] - terms[1] / terms[2]) / numel_total
+    return nll, Z, logdet
+
+
+def allreduce_nll(terms, group=None):
+    """Sum the [sum z^2, sum logdet, B] vector over the data-parallel ranks (no-op without torch.distributed)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(terms, op=dist.ReduceOp.SUM, group=group)
+    return terms
+
+
+def build_networks(n_depths=96, side=512, max_down_steps=5, block_type="CAT", n_blocks=4, internal_chans=64,
+                   cond_chans=32, use_perm=True, use_bias=True, with_lrnn=True, device="cuda"):
+    """Build the model list the way run_CWFA does (CWFA.py:478-532): one (GraphINN, cond_network) per flow step and the
+    LRNN Encoder as the last condition net.  Flow nets and condition nets in eval mode, the LRNN in train mode."""
+    from . import networks as N
+    conv_inn, cond_nets = [], []
+    for ix in range(max_down_steps - 1):
+        cn = n_depths // (2 ** (ix + 1))
+        cond_net, inns = N.conditional_wavelet_flow(
+            input_volume_shape=[n_depths, side, side], condition_shape=[1, 29, side, side],
+            st_subnet=N.wavelet_flow_subnetwork2D,
+            conditional_network=lambda: N.cond_network(29, cn, ix + 1, max_down_steps, [], cond_chans),
+            n_internal_ch=internal_chans, n_down_steps=ix + 1, use_permutations=use_perm, block_type=block_type,
+            n_blocks=n_blocks, device="cpu")
+        conv_inn.append(inns[ix].eval().to(device))
+        cond_nets.append(cond_net.eval().to(device))
+    if with_lrnn:
+        enc = N.Encoder(29, n_depths // (2 ** (max_down_steps - 1)), max_down_steps, internal_chans, use_bias).to(device)
+        enc.train()                                     # CWFA.py:532: BatchNorm batch statistics, dropout, drop_path
+        cond_nets.append(enc)
+    return conv_inn, cond_nets

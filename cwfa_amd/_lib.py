@@ -1,0 +1,94 @@
+"""ctypes binding of libcwfa_hip.so (C ABI: include/cwfa_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved, importing an op raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcwfa_hip.so")
+
+CLAMP = {"NONE": 0, "ATAN": 1, "TANH": 2, "SIGMOID": 3}
+ACT = {None: 0, "none": 0, "elu": 1, "prelu": 2, "gelu": 3, "relu": 4}
+CHAIN_MAX = 8
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_f64p = C.c_void_p
+
+
+class AffineStage(C.Structure):
+    _fields_ = [("s_raw", c_f32p), ("t", c_f32p), ("s_bs", C.c_int64), ("t_bs", C.c_int64), ("clamp_kind", C.c_int),
+                ("clamp", C.c_float), ("pre_scale", C.c_float), ("t_neg_div_sqrt2", C.c_int), ("perm", c_i64p),
+                ("perm_axis", C.c_int), ("gin", C.c_int)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("n_stages", C.c_int), ("stage", AffineStage * CHAIN_MAX)]
+
+
+class ConvOpts(C.Structure):
+    _fields_ = [("bias", c_f32p), ("act", C.c_int), ("prelu_alpha", c_f32p), ("residual", c_f32p), ("res_bs", C.c_int64),
+                ("act2", C.c_int), ("in_scale", c_f32p), ("in_shift", c_f32p), ("in_affine_bs", C.c_int), ("in_add", c_f32p),
+                ("in_add_bs", C.c_int64), ("upshuffle2", C.c_int)]
+
+
+# name -> (restype, argtypes); must list EVERY function declared in include/cwfa_hip.h (tests/test_boundary.py checks)
+i, i64, f, d, p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
+SIGNATURES = {
+    "cwfa_version": (i, []),
+    "cwfa_last_error": (C.c_char_p, []),
+    "cwfa_haar1d_fwd_f32": (i, [p, p, p, i, i, i64, i64, i64, i64, p]),
+    "cwfa_haar1d_inv_f32": (i, [p, p, p, i, i, i64, i64, i64, i64, p]),
+    "cwfa_haar2d_fwd_f32": (i, [p, p, i, i, i, i, i, f, p]),
+    "cwfa_haar2d_inv_f32": (i, [p, p, i, i, i, i, i, f, p]),
+    "cwfa_gather_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, p]),
+    "cwfa_affine_f32": (i, [p, p, C.POINTER(AffineStage), i, i, i, i, i, i64, i64, p, p, p]),
+    "cwfa_channel_affine_f32": (i, [p, p, p, p, i, p, p, i, i, i64, i64, i64, p]),
+    "cwfa_chain_inv_f32": (i, [p, p, p, C.POINTER(Chain), i, i, i, i, i64, i64, i64, p, p]),
+    "cwfa_chain_fwd_f32": (i, [p, p, p, C.POINTER(Chain), p, i, i, i, i, i64, i64, i64, p, p, p]),
+    "cwfa_conv2d_packed_floats": (i64, [i, i, i]),
+    "cwfa_conv2d_pack_f32": (i, [p, p, i, i, i, i, p]),
+    "cwfa_conv2d_f32": (i, [p, p, p, i, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_conv3d_1k1_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
+    "cwfa_channel_stats_f32": (i, [p, p, i, i, i64, i64, p]),
+    "cwfa_bn_fold_f32": (i, [p, d, p, p, p, p, f, p, i, p, p, i, p]),
+    "cwfa_maxpool_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, p]),
+    "cwfa_sample_stats_f32": (i, [p, p, i, i64, p]),
+    "cwfa_layernorm_apply_f32": (i, [p, p, p, p, f, p, i, i64, p]),
+    "cwfa_attention_combine_f32": (i, [p, p, p, p, p, p, p, p, i, i, i64, p]),
+    "cwfa_scale_channels_f32": (i, [p, p, p, i, i, i64, p]),
+    "cwfa_axpby_f32": (i, [p, p, f, f, p, i64, p]),
+}
+del i, i64, f, d, p
+
+_lib = None
+
+
+class CwfaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CwfaHipError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m cwfa_amd.build, or "
+                f"__graft_entry__.build()).  cwfa_amd has no CPU / PyTorch fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the symbol is missing -> loud
+            fn.restype = res
+            fn.argtypes = args
+        if h.cwfa_version() < 100:
+            raise CwfaHipError("libcwfa_hip.so is older than this Python layer")
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cwfa_last_error()
+        raise CwfaHipError(f"{what or 'libcwfa_hip'} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,69 @@
+// Shared helpers for the libcwfa_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cwfa_hip.h"
+
+void cwfa_set_error(const char* fmt, ...);
+
+#define CWFA_REQUIRE(cond, code, ...)        \
+    do {                                     \
+        if (!(cond)) {                       \
+            cwfa_set_error(__VA_ARGS__);     \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define CWFA_LAUNCH_CHECK(name)                                              \
+    do {                                                                     \
+        hipError_t e_ = hipGetLastError();                                   \
+        if (e_ != hipSuccess) {                                              \
+            cwfa_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return CWFA_E_HIP;                                               \
+        }                                                                    \
+    } while (0)
+
+static inline bool cwfa_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// fp32 constant the reference multiplies with: python float 1/math.sqrt(2) rounded to fp32 (INN_utils.py:150,161)
+#define CWFA_INV_SQRT2_F 0.70710678118654752440f
+// fp32(math.sqrt(2)) used as a divisor in networks.py:671
+#define CWFA_SQRT2_F 1.41421356237309504880f
+
+// wave64 sum, result valid in every lane
+__device__ __forceinline__ double cwfa_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float cwfa_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of doubles (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
+__device__ __forceinline__ double cwfa_block_sum(double v, double* lds /* >= 16 doubles */) {
+    v = cwfa_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += lds[i];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float cwfa_elu(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float cwfa_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float cwfa_act(float v, int act, float alpha) {
+    switch (act) {
+        case CWFA_ACT_ELU: return cwfa_elu(v);
+        case CWFA_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case CWFA_ACT_GELU: return cwfa_gelu(v);
+        case CWFA_ACT_RELU: return v > 0.f ? v : 0.f;
+        default: return v;
+    }
+}

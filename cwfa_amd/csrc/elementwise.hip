@@ -1,0 +1,558 @@
+// HBM-bound streaming kernels of the flow stack: Haar wavelets, index gathers, affine coupling apply,
+// and the fused per-step chains.  Compiled with -ffp-contract=off so that the two-op sequences of the
+// reference ((a+b)*f, exp(s)*x+t, (x-t)*exp(-s)) round exactly like the reference's separate torch ops.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+// ------------------------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+
+void cwfa_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int cwfa_version(void) { return CWFA_VERSION; }
+extern "C" const char* cwfa_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ Haar 1-D (depth)
+// One thread = VEC consecutive pixels of one channel PAIR: 2 loads + 2 stores of VEC*4 bytes each, all coalesced.
+// Algorithmic traffic: 8 bytes per input element (read once, write once) -- the HBM roofline of DESIGN.md.
+template <int VEC>
+__global__ __launch_bounds__(256) void haar1d_fwd_kernel(const float* __restrict__ x, float* __restrict__ lo,
+                                                         float* __restrict__ hi, int h, int64_t HWv, int64_t HW,
+                                                         int64_t x_bs, int64_t lo_bs, int64_t hi_bs) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HWv) return;
+    const int i = blockIdx.y, b = blockIdx.z;
+    const vec_t e = *reinterpret_cast<const vec_t*>(x + b * x_bs + (int64_t)(2 * i) * HW + p * VEC);
+    const vec_t o = *reinterpret_cast<const vec_t*>(x + b * x_bs + (int64_t)(2 * i + 1) * HW + p * VEC);
+    *reinterpret_cast<vec_t*>(lo + b * lo_bs + (int64_t)i * HW + p * VEC) = (e + o) * CWFA_INV_SQRT2_F;
+    *reinterpret_cast<vec_t*>(hi + b * hi_bs + (int64_t)i * HW + p * VEC) = (e - o) * CWFA_INV_SQRT2_F;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void haar1d_inv_kernel(const float* __restrict__ lo, const float* __restrict__ hi,
+                                                         float* __restrict__ x, int h, int64_t HWv, int64_t HW,
+                                                         int64_t lo_bs, int64_t hi_bs, int64_t x_bs) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HWv) return;
+    const int i = blockIdx.y, b = blockIdx.z;
+    const vec_t l = *reinterpret_cast<const vec_t*>(lo + b * lo_bs + (int64_t)i * HW + p * VEC);
+    vec_t d = (vec_t)(0.f);
+    if (hi) d = *reinterpret_cast<const vec_t*>(hi + b * hi_bs + (int64_t)i * HW + p * VEC);
+    *reinterpret_cast<vec_t*>(x + b * x_bs + (int64_t)(2 * i) * HW + p * VEC) = (l + d) * CWFA_INV_SQRT2_F;
+    *reinterpret_cast<vec_t*>(x + b * x_bs + (int64_t)(2 * i + 1) * HW + p * VEC) = (l - d) * CWFA_INV_SQRT2_F;
+}
+
+static int haar1d_check(const char* name, const void* a, const void* b, const void* c, int B, int D, int64_t HW) {
+    CWFA_REQUIRE(a && c, CWFA_E_INVAL, "%s: null pointer", name);
+    CWFA_REQUIRE(B >= 0 && D >= 0 && HW >= 0, CWFA_E_INVAL, "%s: negative size", name);
+    CWFA_REQUIRE(D % 2 == 0, CWFA_E_SHAPE, "%s: depth %d is odd", name, D);
+    CWFA_REQUIRE(D / 2 <= 65535 && B <= 65535, CWFA_E_SHAPE, "%s: grid too large (D/2=%d, B=%d)", name, D / 2, B);
+    (void)b;
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_haar1d_fwd_f32(const float* x, float* lo, float* hi, int B, int D, int64_t HW, int64_t x_bs,
+                                   int64_t lo_bs, int64_t hi_bs, void* stream) {
+    int rc = haar1d_check("cwfa_haar1d_fwd_f32", x, lo, hi, B, D, HW);
+    if (rc) return rc;
+    CWFA_REQUIRE(lo && hi, CWFA_E_INVAL, "cwfa_haar1d_fwd_f32: null output");
+    if (B == 0 || D == 0 || HW == 0) return CWFA_OK;
+    const int h = D / 2;
+    const bool v4 = HW % 4 == 0 && x_bs % 4 == 0 && lo_bs % 4 == 0 && hi_bs % 4 == 0 && cwfa_aligned16(x) &&
+                    cwfa_aligned16(lo) && cwfa_aligned16(hi);
+    const int64_t HWv = v4 ? HW / 4 : HW;
+    dim3 grid((unsigned)((HWv + 255) / 256), h, B);
+    if (v4)
+        hipLaunchKernelGGL(haar1d_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, lo, hi, h, HWv, HW, x_bs,
+                           lo_bs, hi_bs);
+    else
+        hipLaunchKernelGGL(haar1d_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, lo, hi, h, HWv, HW, x_bs,
+                           lo_bs, hi_bs);
+    CWFA_LAUNCH_CHECK("cwfa_haar1d_fwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_haar1d_inv_f32(const float* lo, const float* hi, float* x, int B, int D, int64_t HW, int64_t lo_bs,
+                                   int64_t hi_bs, int64_t x_bs, void* stream) {
+    int rc = haar1d_check("cwfa_haar1d_inv_f32", lo, hi, x, B, D, HW);
+    if (rc) return rc;
+    if (B == 0 || D == 0 || HW == 0) return CWFA_OK;
+    const int h = D / 2;
+    const bool v4 = HW % 4 == 0 && x_bs % 4 == 0 && lo_bs % 4 == 0 && (hi == nullptr || hi_bs % 4 == 0) &&
+                    cwfa_aligned16(x) && cwfa_aligned16(lo) && cwfa_aligned16(hi);
+    const int64_t HWv = v4 ? HW / 4 : HW;
+    dim3 grid((unsigned)((HWv + 255) / 256), h, B);
+    if (v4)
+        hipLaunchKernelGGL(haar1d_inv_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, lo, hi, x, h, HWv, HW, lo_bs,
+                           hi_bs, x_bs);
+    else
+        hipLaunchKernelGGL(haar1d_inv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, lo, hi, x, h, HWv, HW, lo_bs,
+                           hi_bs, x_bs);
+    CWFA_LAUNCH_CHECK("cwfa_haar1d_inv_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Haar 2-D (spatial)
+// One thread = one 2x2 input patch of one channel = one output pixel of the 4 wavelet channels.
+// The sum order matches a 2x2 conv's natural accumulation (p00, p01, p10, p11) of reshapes.py:282.
+__global__ __launch_bounds__(256) void haar2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H,
+                                                         int W, int obw, float fac) {
+    const int h2 = H / 2, w2 = W / 2;
+    const int64_t n = (int64_t)C * h2 * w2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const int wx = (int)(i % w2), hy = (int)((i / w2) % h2), c = (int)(i / ((int64_t)w2 * h2));
+    const float* px = x + ((int64_t)b * C + c) * H * W + (int64_t)(2 * hy) * W + 2 * wx;
+    const float2 r0 = *reinterpret_cast<const float2*>(px);
+    const float2 r1 = *reinterpret_cast<const float2*>(px + W);
+    const float a = ((r0.x + r0.y) + r1.x) + r1.y;
+    const float v1 = ((r0.x - r0.y) + r1.x) - r1.y;
+    const float v2 = ((r0.x + r0.y) - r1.x) - r1.y;
+    const float d = ((r0.x - r0.y) - r1.x) + r1.y;
+    const int64_t plane = (int64_t)h2 * w2, pos = (int64_t)hy * w2 + wx;
+    float* py = y + (int64_t)b * 4 * C * plane + pos;
+    const int c0 = obw ? c : 4 * c, cs = obw ? C : 1;
+    py[(int64_t)(c0)*plane] = a * fac;
+    py[(int64_t)(c0 + cs) * plane] = v1 * fac;
+    py[(int64_t)(c0 + 2 * cs) * plane] = v2 * fac;
+    py[(int64_t)(c0 + 3 * cs) * plane] = d * fac;
+}
+
+__global__ __launch_bounds__(256) void haar2d_inv_kernel(const float* __restrict__ y, float* __restrict__ x, int C, int H,
+                                                         int W, int obw, float fac) {
+    const int h2 = H / 2, w2 = W / 2;
+    const int64_t n = (int64_t)C * h2 * w2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const int wx = (int)(i % w2), hy = (int)((i / w2) % h2), c = (int)(i / ((int64_t)w2 * h2));
+    const int64_t plane = (int64_t)h2 * w2, pos = (int64_t)hy * w2 + wx;
+    const float* py = y + (int64_t)b * 4 * C * plane + pos;
+    const int c0 = obw ? c : 4 * c, cs = obw ? C : 1;
+    const float a = py[(int64_t)(c0)*plane] * fac;
+    const float v1 = py[(int64_t)(c0 + cs) * plane] * fac;
+    const float v2 = py[(int64_t)(c0 + 2 * cs) * plane] * fac;
+    const float d = py[(int64_t)(c0 + 3 * cs) * plane] * fac;
+    float* px = x + ((int64_t)b * C + c) * H * W + (int64_t)(2 * hy) * W + 2 * wx;
+    *reinterpret_cast<float2*>(px) = make_float2(((a + v1) + v2) + d, ((a - v1) + v2) - d);
+    *reinterpret_cast<float2*>(px + W) = make_float2(((a + v1) - v2) - d, ((a - v1) - v2) + d);
+}
+
+static int haar2d_launch(bool fwd, const float* a, float* b, int B, int C, int H, int W, int obw, float fac,
+                         void* stream) {
+    const char* name = fwd ? "cwfa_haar2d_fwd_f32" : "cwfa_haar2d_inv_f32";
+    CWFA_REQUIRE(a && b, CWFA_E_INVAL, "%s: null pointer", name);
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "%s: negative size", name);
+    CWFA_REQUIRE(H % 2 == 0 && W % 2 == 0, CWFA_E_SHAPE, "%s: H=%d, W=%d must be even", name, H, W);
+    CWFA_REQUIRE(B <= 65535, CWFA_E_SHAPE, "%s: batch too large", name);
+    if (B == 0 || C == 0 || H == 0 || W == 0) return CWFA_OK;
+    const int64_t n = (int64_t)C * (H / 2) * (W / 2);
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    if (fwd)
+        hipLaunchKernelGGL(haar2d_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, C, H, W, obw, fac);
+    else
+        hipLaunchKernelGGL(haar2d_inv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, C, H, W, obw, fac);
+    CWFA_LAUNCH_CHECK(name);
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_haar2d_fwd_f32(const float* x, float* y, int B, int C, int H, int W, int order_by_wavelet, float fac,
+                                   void* stream) {
+    return haar2d_launch(true, x, y, B, C, H, W, order_by_wavelet, fac, stream);
+}
+extern "C" int cwfa_haar2d_inv_f32(const float* y, float* x, int B, int C, int H, int W, int order_by_wavelet, float fac,
+                                   void* stream) {
+    return haar2d_launch(false, y, x, B, C, H, W, order_by_wavelet, fac, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ gathers
+struct Pos {
+    int c, h, w;
+};
+
+__device__ __forceinline__ Pos gather_pos(Pos p, const int64_t* __restrict__ perm, int axis) {
+    if (perm) {
+        if (axis == 1)
+            p.c = (int)perm[p.c];
+        else if (axis == 2)
+            p.h = (int)perm[p.h];
+        else
+            p.w = (int)perm[p.w];
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ x, const int64_t* __restrict__ perm,
+                                                     float* __restrict__ y, int C, int H, int W, int axis, int64_t x_bs,
+                                                     int64_t y_bs) {
+    const int64_t n = (int64_t)C * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    Pos p{(int)(i / ((int64_t)H * W)), (int)((i / W) % H), (int)(i % W)};
+    const Pos q = gather_pos(p, perm, axis);
+    y[b * y_bs + i] = x[b * x_bs + ((int64_t)q.c * H + q.h) * W + q.w];
+}
+
+static int check_perm_axis(const char* name, int axis) {
+    CWFA_REQUIRE(axis >= 1 && axis <= 3, CWFA_E_INVAL, "%s: axis %d not in 1..3", name, axis);
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_gather_f32(const float* x, const int64_t* perm, float* y, int B, int C, int H, int W, int axis,
+                               int64_t x_bs, int64_t y_bs, void* stream) {
+    CWFA_REQUIRE(x && y && perm, CWFA_E_INVAL, "cwfa_gather_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_gather_f32: negative size");
+    CWFA_REQUIRE(B <= 65535, CWFA_E_SHAPE, "cwfa_gather_f32: batch too large");
+    int rc = check_perm_axis("cwfa_gather_f32", axis);
+    if (rc) return rc;
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, perm, y, C, H, W, axis, x_bs, y_bs);
+    CWFA_LAUNCH_CHECK("cwfa_gather_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ affine apply
+__device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
+    switch (kind) {
+        case CWFA_CLAMP_ATAN: return clamp * (0.636f * atanf(a));
+        case CWFA_CLAMP_TANH: return clamp * tanhf(a);
+        case CWFA_CLAMP_SIGMOID: return clamp * (2.f * (1.f / (1.f + expf(-a)) - 0.5f));
+        default: return clamp * a;
+    }
+}
+
+// read s (clamped) and t of a stage at linear in-sample offset `off`
+__device__ __forceinline__ void stage_st(const cwfa_affine_stage& st, int b, int64_t off, float& s, float& t) {
+    s = 0.f;
+    t = 0.f;
+    if (st.s_raw) s = soft_clamp(st.s_raw[b * st.s_bs + off] * st.pre_scale, st.clamp_kind, st.clamp);
+    if (st.t) {
+        const float tv = st.t[b * st.t_bs + off];
+        t = st.t_neg_div_sqrt2 ? (-tv) / CWFA_SQRT2_F : tv * st.pre_scale;
+    }
+}
+
+__device__ __forceinline__ float affine_apply(float v, float s, float t, int rev) {
+    return rev ? (v - t) * expf(-s) : expf(s) * v + t;
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     cwfa_affine_stage st, int rev, int C, int H, int W, int64_t x_bs,
+                                                     int64_t y_bs, double* __restrict__ logdet,
+                                                     double* __restrict__ sumsq) {
+    __shared__ double red[16];
+    const int64_t n = (int64_t)C * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    float s = 0.f, out = 0.f;
+    if (i < n) {
+        Pos p{(int)(i / ((int64_t)H * W)), (int)((i / W) % H), (int)(i % W)};
+        const Pos q = gather_pos(p, st.perm, st.perm_axis);
+        const float v = x ? x[b * x_bs + ((int64_t)q.c * H + q.h) * W + q.w] : 0.f;
+        float t;
+        stage_st(st, b, i, s, t);
+        out = affine_apply(v, s, t, rev);
+        y[b * y_bs + i] = out;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)s, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], rev ? -tot : tot);
+    }
+    if (sumsq) {
+        const double tot = cwfa_block_sum((double)out * (double)out, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq, tot);
+    }
+}
+
+// GIN variant: the channel mean of s is removed at every pixel (coupling_layers.py:355,372); one thread per pixel.
+__global__ __launch_bounds__(256) void affine_gin_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         cwfa_affine_stage st, int rev, int C, int H, int W,
+                                                         int64_t x_bs, int64_t y_bs, double* __restrict__ sumsq) {
+    __shared__ double red[16];
+    const int64_t HW = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    double sq = 0.0;
+    if (i < HW) {
+        float mean = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float s, t;
+            stage_st(st, b, c * HW + i, s, t);
+            mean += s;
+        }
+        mean /= (float)C;
+        const int h = (int)(i / W), w = (int)(i % W);
+        for (int c = 0; c < C; ++c) {
+            float s, t;
+            stage_st(st, b, c * HW + i, s, t);
+            s -= mean;
+            const Pos q = gather_pos(Pos{c, h, w}, st.perm, st.perm_axis);
+            const float v = x ? x[b * x_bs + ((int64_t)q.c * H + q.h) * W + q.w] : 0.f;
+            const float out = affine_apply(v, s, t, rev);
+            y[b * y_bs + c * HW + i] = out;
+            sq += (double)out * (double)out;
+        }
+    }
+    if (sumsq) {
+        const double tot = cwfa_block_sum(sq, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq, tot);
+    }
+}
+
+static int check_stage(const char* name, const cwfa_affine_stage& st) {
+    CWFA_REQUIRE(st.clamp_kind >= CWFA_CLAMP_NONE && st.clamp_kind <= CWFA_CLAMP_SIGMOID, CWFA_E_INVAL,
+                 "%s: bad clamp kind %d", name, st.clamp_kind);
+    if (st.perm) {
+        int rc = check_perm_axis(name, st.perm_axis);
+        if (rc) return rc;
+    }
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_affine_f32(const float* x, float* y, const cwfa_affine_stage* st, int rev, int B, int C, int H, int W,
+                               int64_t x_bs, int64_t y_bs, double* logdet, double* sumsq, void* stream) {
+    CWFA_REQUIRE(y && st, CWFA_E_INVAL, "cwfa_affine_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_affine_f32: negative size");
+    CWFA_REQUIRE(B <= 65535, CWFA_E_SHAPE, "cwfa_affine_f32: batch too large");
+    int rc = check_stage("cwfa_affine_f32", *st);
+    if (rc) return rc;
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    if (st->gin) {
+        CWFA_REQUIRE(st->s_raw, CWFA_E_INVAL, "cwfa_affine_f32: GIN needs s_raw");
+        dim3 grid((unsigned)(((int64_t)H * W + 255) / 256), B);
+        hipLaunchKernelGGL(affine_gin_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, *st, rev, C, H, W, x_bs, y_bs,
+                           sumsq);
+    } else {
+        dim3 grid((unsigned)((n + 255) / 256), B);
+        hipLaunchKernelGGL(affine_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, *st, rev, C, H, W, x_bs, y_bs,
+                           logdet, sumsq);
+    }
+    CWFA_LAUNCH_CHECK("cwfa_affine_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-channel affine
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int mode,
+                                                             const int64_t* __restrict__ perm_in,
+                                                             const int64_t* __restrict__ perm_out, int C, int64_t HW,
+                                                             int64_t x_bs, int64_t y_bs) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    // channel whose affine parameters apply, and channel read from the input
+    const int cp = perm_out ? (int)perm_out[c] : c;         // parameters follow the pre-permutation channel
+    const int cr = perm_in ? (int)perm_in[c] : cp;
+    const float v = x[b * x_bs + (int64_t)cr * HW + p];
+    const float sc = scale ? scale[cp] : 1.f, sh = shift ? shift[cp] : 0.f;
+    y[b * y_bs + (int64_t)c * HW + p] = mode == 0 ? v * sc + sh : (v - sh) / sc;
+}
+
+extern "C" int cwfa_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int mode,
+                                       const int64_t* perm_in, const int64_t* perm_out, int B, int C, int64_t HW,
+                                       int64_t x_bs, int64_t y_bs, void* stream) {
+    CWFA_REQUIRE(x && y, CWFA_E_INVAL, "cwfa_channel_affine_f32: null pointer");
+    CWFA_REQUIRE(!(perm_in && perm_out), CWFA_E_INVAL, "cwfa_channel_affine_f32: both perm_in and perm_out given");
+    CWFA_REQUIRE(mode == 0 || mode == 1, CWFA_E_INVAL, "cwfa_channel_affine_f32: bad mode");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C <= 65535 && B <= 65535, CWFA_E_SHAPE,
+                 "cwfa_channel_affine_f32: bad shape");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    dim3 grid((unsigned)((HW + 255) / 256), C, B);
+    hipLaunchKernelGGL(channel_affine_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, scale, shift, mode, perm_in,
+                       perm_out, C, HW, x_bs, y_bs);
+    CWFA_LAUNCH_CHECK("cwfa_channel_affine_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fused chains
+// Every stage is a pull:  v_{k+1}[p] = A_k(v_k[g_k(p)], s_k[p], t_k[p]).  A thread owns ONE final position, walks the
+// gathers backwards to find where its value starts, then applies the affines forwards.  Each (stage, position) pair is
+// visited by exactly one thread, so block-reducing the s values gives the exact per-sample log-det.
+__device__ __forceinline__ int64_t lin(Pos p, int H, int W) { return ((int64_t)p.c * H + p.h) * W + p.w; }
+
+__global__ __launch_bounds__(256) void chain_inv_kernel(const float* __restrict__ z, const float* __restrict__ low,
+                                                        float* __restrict__ x, cwfa_chain ch, int C, int H, int W,
+                                                        int64_t z_bs, int64_t low_bs, int64_t x_bs,
+                                                        double* __restrict__ logdet) {
+    __shared__ double red[16];
+    const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    float ssum = 0.f;
+    if (i < n) {
+        Pos p{(int)(i / HW), (int)((i / W) % H), (int)(i % W)};
+        int64_t off[CWFA_CHAIN_MAX];
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k) {
+            if (k < ch.n_stages) {
+                off[k] = lin(p, H, W);
+                p = gather_pos(p, ch.stage[k].perm, ch.stage[k].perm_axis);
+            }
+        }
+        float v = z ? z[b * z_bs + lin(p, H, W)] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k) {
+            if (k < ch.n_stages) {
+                float s, t;
+                stage_st(ch.stage[k], b, off[k], s, t);
+                v = affine_apply(v, s, t, 1);
+                ssum += s;
+            }
+        }
+        const int c = (int)(i / HW);
+        const int64_t pix = i - (int64_t)c * HW;
+        const float l = low[b * low_bs + i];
+        x[b * x_bs + (int64_t)(2 * c) * HW + pix] = (l + v) * CWFA_INV_SQRT2_F;
+        x[b * x_bs + (int64_t)(2 * c + 1) * HW + pix] = (l - v) * CWFA_INV_SQRT2_F;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)ssum, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], -tot);
+    }
+}
+
+__global__ __launch_bounds__(256) void chain_fwd_kernel(const float* __restrict__ x, float* __restrict__ low,
+                                                        float* __restrict__ zout, cwfa_chain ch,
+                                                        const int64_t* __restrict__ final_perm, int C, int H, int W,
+                                                        int64_t x_bs, int64_t low_bs, int64_t z_bs,
+                                                        double* __restrict__ logdet, double* __restrict__ sumsq) {
+    __shared__ double red[16];
+    const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    float ssum = 0.f, v = 0.f;
+    if (i < n) {
+        Pos p{(int)(i / HW), (int)((i / W) % H), (int)(i % W)};
+        {   // the low-pass half at this thread's own position (Split.out0, networks.py:364)
+            const int64_t pix = i - (int64_t)p.c * HW;
+            const float e = x[b * x_bs + (int64_t)(2 * p.c) * HW + pix], o = x[b * x_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+            low[b * low_bs + i] = (e + o) * CWFA_INV_SQRT2_F;
+        }
+        p = gather_pos(p, final_perm, 1);
+        int64_t off[CWFA_CHAIN_MAX];
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k) {
+            if (k < ch.n_stages) {
+                off[k] = lin(p, H, W);
+                p = gather_pos(p, ch.stage[k].perm, ch.stage[k].perm_axis);
+            }
+        }
+        {   // the detail half where this thread's value starts
+            const int64_t pix = (int64_t)p.h * W + p.w;
+            const float e = x[b * x_bs + (int64_t)(2 * p.c) * HW + pix], o = x[b * x_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+            v = (e - o) * CWFA_INV_SQRT2_F;
+        }
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k) {
+            if (k < ch.n_stages) {
+                float s, t;
+                stage_st(ch.stage[k], b, off[k], s, t);
+                v = affine_apply(v, s, t, 0);
+                ssum += s;
+            }
+        }
+        zout[b * z_bs + i] = v;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)ssum, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], tot);
+    }
+    if (sumsq) {
+        const double tot = cwfa_block_sum((double)v * (double)v, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq, tot);
+    }
+}
+
+static int check_chain(const char* name, const cwfa_chain* ch) {
+    CWFA_REQUIRE(ch, CWFA_E_INVAL, "%s: null chain", name);
+    CWFA_REQUIRE(ch->n_stages >= 0 && ch->n_stages <= CWFA_CHAIN_MAX, CWFA_E_INVAL, "%s: %d stages (max %d)", name,
+                 ch->n_stages, CWFA_CHAIN_MAX);
+    for (int k = 0; k < ch->n_stages; ++k) {
+        int rc = check_stage(name, ch->stage[k]);
+        if (rc) return rc;
+        CWFA_REQUIRE(!ch->stage[k].gin, CWFA_E_INVAL, "%s: GIN stages cannot be chained", name);
+    }
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_chain_inv_f32(const float* z, const float* low, float* x, const cwfa_chain* ch, int B, int C, int H,
+                                  int W, int64_t z_bs, int64_t low_bs, int64_t x_bs, double* logdet, void* stream) {
+    CWFA_REQUIRE(low && x, CWFA_E_INVAL, "cwfa_chain_inv_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_inv_f32: bad shape");
+    int rc = check_chain("cwfa_chain_inv_f32", ch);
+    if (rc) return rc;
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(chain_inv_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, low, x, *ch, C, H, W, z_bs, low_bs, x_bs,
+                       logdet);
+    CWFA_LAUNCH_CHECK("cwfa_chain_inv_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cwfa_chain* ch, const int64_t* final_perm,
+                                  int B, int C, int H, int W, int64_t x_bs, int64_t low_bs, int64_t z_bs, double* logdet,
+                                  double* sumsq, void* stream) {
+    CWFA_REQUIRE(x && low && z, CWFA_E_INVAL, "cwfa_chain_fwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_fwd_f32: bad shape");
+    int rc = check_chain("cwfa_chain_fwd_f32", ch);
+    if (rc) return rc;
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(chain_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, low, z, *ch, final_perm, C, H, W, x_bs,
+                       low_bs, z_bs, logdet, sumsq);
+    CWFA_LAUNCH_CHECK("cwfa_chain_fwd_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                             float* __restrict__ y, int64_t HW) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int64_t bc = blockIdx.y;
+    y[bc * HW + p] = x[bc * HW + p] * sc[bc];
+}
+
+extern "C" int cwfa_scale_channels_f32(const float* x, const float* scale_bc, float* y, int B, int C, int64_t HW,
+                                       void* stream) {
+    CWFA_REQUIRE(x && y && scale_bc, CWFA_E_INVAL, "cwfa_scale_channels_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && (int64_t)B * C <= 65535, CWFA_E_SHAPE, "cwfa_scale_channels_f32: bad shape");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    dim3 grid((unsigned)((HW + 255) / 256), B * C);
+    hipLaunchKernelGGL(scale_channels_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, scale_bc, y, HW);
+    CWFA_LAUNCH_CHECK("cwfa_scale_channels_f32");
+    return CWFA_OK;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ z, float a,
+                                                    float bb, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = z ? a * x[i] + bb * z[i] : a * x[i];
+}
+
+extern "C" int cwfa_axpby_f32(const float* x, const float* z, float a, float b, float* y, int64_t n, void* stream) {
+    CWFA_REQUIRE(x && y, CWFA_E_INVAL, "cwfa_axpby_f32: null pointer");
+    CWFA_REQUIRE(n >= 0, CWFA_E_INVAL, "cwfa_axpby_f32: negative size");
+    if (n == 0) return CWFA_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, z, a, b, y, n);
+    CWFA_LAUNCH_CHECK("cwfa_axpby_f32");
+    return CWFA_OK;
+}

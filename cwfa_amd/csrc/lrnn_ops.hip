@@ -1,0 +1,231 @@
+// Small HBM-bound kernels of the LRNN (UNet + ConvNeXt + GlobalAttention): normalisation statistics and applies,
+// adaptive max-pool, attention/combine.  The convolutions themselves are in conv2d.hip.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ BatchNorm statistics
+// grid (splits, C): each block sums a slice of the (B, HW) elements of channel c and adds (sum, sumsq) in double.
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int B,
+                                                            int64_t HW, int64_t x_bs) {
+    __shared__ double red[16];
+    const int c = blockIdx.y;
+    const int64_t total = (int64_t)B * HW;
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, p = i - b * HW;
+        const float v = x[b * x_bs + (int64_t)c * HW + p];
+        s += v;
+        q += (double)v * v;
+    }
+    s = cwfa_block_sum(s, red);
+    q = cwfa_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * c], s);
+        atomicAdd(&stats[2 * c + 1], q);
+    }
+}
+
+extern "C" int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream) {
+    CWFA_REQUIRE(x && stats, CWFA_E_INVAL, "cwfa_channel_stats_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C <= 65535, CWFA_E_SHAPE, "cwfa_channel_stats_f32: bad shape");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    const int64_t total = (int64_t)B * HW;
+    int splits = (int)((total + 256 * 16 - 1) / (256 * 16));
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(splits, C), dim3(256), 0, (hipStream_t)stream, x, stats, B, HW, x_bs);
+    CWFA_LAUNCH_CHECK("cwfa_channel_stats_f32");
+    return CWFA_OK;
+}
+
+__global__ void bn_fold_kernel(const double* __restrict__ stats, double count, const float* __restrict__ rm,
+                               const float* __restrict__ rv, const float* __restrict__ w, const float* __restrict__ bsh,
+                               float eps, const float* __restrict__ mask, int B, float* __restrict__ scale,
+                               float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sc = 1.0, sh = 0.0;
+    if (stats || rm) {
+        double mean, var;
+        if (stats) {
+            mean = stats[2 * c] / count;
+            var = stats[2 * c + 1] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else {
+            mean = rm[c];
+            var = rv[c];
+        }
+        sc = (w ? (double)w[c] : 1.0) / sqrt(var + (double)eps);
+        sh = (bsh ? (double)bsh[c] : 0.0) - mean * sc;
+    }
+    if (mask) {
+        for (int b = 0; b < B; ++b) {
+            const float m = mask[b * C + c];
+            scale[b * C + c] = (float)sc * m;
+            shift[b * C + c] = (float)sh * m;
+        }
+    } else {
+        scale[c] = (float)sc;
+        shift[c] = (float)sh;
+    }
+}
+
+extern "C" int cwfa_bn_fold_f32(const double* stats, double count, const float* running_mean, const float* running_var,
+                                const float* weight, const float* bias, float eps, const float* mask_bc, int B, float* scale,
+                                float* shift, int C, void* stream) {
+    CWFA_REQUIRE(scale && shift, CWFA_E_INVAL, "cwfa_bn_fold_f32: null output");
+    CWFA_REQUIRE(stats || (running_mean && running_var) || mask_bc, CWFA_E_INVAL,
+                 "cwfa_bn_fold_f32: neither batch nor running statistics nor a mask");
+    CWFA_REQUIRE(!running_mean == !running_var, CWFA_E_INVAL, "cwfa_bn_fold_f32: running_mean and running_var go together");
+    CWFA_REQUIRE(!mask_bc || B > 0, CWFA_E_INVAL, "cwfa_bn_fold_f32: mask needs B > 0");
+    CWFA_REQUIRE(!stats || count > 0, CWFA_E_INVAL, "cwfa_bn_fold_f32: count must be positive");
+    CWFA_REQUIRE(C >= 0, CWFA_E_INVAL, "cwfa_bn_fold_f32: negative size");
+    if (C == 0) return CWFA_OK;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, running_mean,
+                       running_var, weight, bias, eps, mask_bc, B, scale, shift, C);
+    CWFA_LAUNCH_CHECK("cwfa_bn_fold_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ adaptive max pool
+// window of output i along a dimension of size n -> m:  [floor(i*n/m), ceil((i+1)*n/m))   (ATen adaptive pooling)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      float* __restrict__ full, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int C, int H, int W, int Ho, int Wo) {
+    const int64_t n = (int64_t)Ho * Wo;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int bc = blockIdx.y, c = bc % C;
+    const int oy = (int)(i / Wo), ox = (int)(i % Wo);
+    const int y0 = (int)(((int64_t)oy * H) / Ho), y1 = (int)((((int64_t)oy + 1) * H + Ho - 1) / Ho);
+    const int x0 = (int)(((int64_t)ox * W) / Wo), x1 = (int)((((int64_t)ox + 1) * W + Wo - 1) / Wo);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const float* px = x + (int64_t)bc * H * W;
+    float* pf = full ? full + (int64_t)bc * H * W : nullptr;
+    float m = -INFINITY;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) {
+            float v = px[(int64_t)yy * W + xx];
+            if (scale) v = v * sc + sh;
+            // overlapping adaptive windows (H % Ho != 0) rewrite the same value: benign
+            if (pf) pf[(int64_t)yy * W + xx] = v;
+            m = (v > m || v != v) ? v : m;      // NaN propagates like ATen
+        }
+    y[(int64_t)bc * n + i] = m;
+}
+
+extern "C" int cwfa_maxpool_f32(const float* x, float* y, float* full, const float* scale, const float* shift, int B, int C,
+                                int H, int W, int Ho, int Wo, void* stream) {
+    CWFA_REQUIRE(x && y, CWFA_E_INVAL, "cwfa_maxpool_f32: null pointer");
+    CWFA_REQUIRE(!(scale && !shift), CWFA_E_INVAL, "cwfa_maxpool_f32: scale without shift");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W, CWFA_E_SHAPE,
+                 "cwfa_maxpool_f32: bad shape");
+    CWFA_REQUIRE((int64_t)B * C <= 65535, CWFA_E_SHAPE, "cwfa_maxpool_f32: B*C too large");
+    if (B == 0 || C == 0) return CWFA_OK;
+    const int64_t n = (int64_t)Ho * Wo;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((n + 255) / 256), B * C), dim3(256), 0, (hipStream_t)stream, x, y, full,
+                       scale, shift, C, H, W, Ho, Wo);
+    CWFA_LAUNCH_CHECK("cwfa_maxpool_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm over (C,H,W)
+__global__ __launch_bounds__(256) void sample_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                           int64_t CHW) {
+    __shared__ double red[16];
+    const int b = blockIdx.y;
+    const float* px = x + (int64_t)b * CHW;
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < CHW; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = px[i];
+        s += v;
+        q += (double)v * v;
+    }
+    s = cwfa_block_sum(s, red);
+    q = cwfa_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * b], s);
+        atomicAdd(&stats[2 * b + 1], q);
+    }
+}
+
+extern "C" int cwfa_sample_stats_f32(const float* x, double* stats, int B, int64_t CHW, void* stream) {
+    CWFA_REQUIRE(x && stats, CWFA_E_INVAL, "cwfa_sample_stats_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && CHW >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_sample_stats_f32: bad shape");
+    if (B == 0 || CHW == 0) return CWFA_OK;
+    int blocks = (int)((CHW + 256 * 16 - 1) / (256 * 16));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sample_stats_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, x, stats, CHW);
+    CWFA_LAUNCH_CHECK("cwfa_sample_stats_f32");
+    return CWFA_OK;
+}
+
+__global__ __launch_bounds__(256) void layernorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                              const float* __restrict__ w, const float* __restrict__ bsh,
+                                                              float eps, float* __restrict__ y, int64_t CHW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CHW) return;
+    const int b = blockIdx.y;
+    const double mean = stats[2 * b] / (double)CHW;
+    double var = stats[2 * b + 1] / (double)CHW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float v = (x[(int64_t)b * CHW + i] - (float)mean) * rstd;
+    y[(int64_t)b * CHW + i] = v * (w ? w[i] : 1.f) + (bsh ? bsh[i] : 0.f);
+}
+
+extern "C" int cwfa_layernorm_apply_f32(const float* x, const double* stats, const float* w, const float* b, float eps,
+                                        float* y, int B, int64_t CHW, void* stream) {
+    CWFA_REQUIRE(x && stats && y, CWFA_E_INVAL, "cwfa_layernorm_apply_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && CHW >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_layernorm_apply_f32: bad shape");
+    if (B == 0 || CHW == 0) return CWFA_OK;
+    hipLaunchKernelGGL(layernorm_apply_kernel, dim3((unsigned)((CHW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x,
+                       stats, w, b, eps, y, CHW);
+    CWFA_LAUNCH_CHECK("cwfa_layernorm_apply_f32");
+    return CWFA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ attention + combine
+#define CWFA_ATT_MAXC 16
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, const float* __restrict__ m,
+                                                                const float* __restrict__ x, float* __restrict__ out, int C,
+                                                                int64_t L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const int b = blockIdx.y;
+    const float* pm = mean + (int64_t)b * C * L;
+    float hid[CWFA_ATT_MAXC];
+    for (int o = 0; o < C; ++o) hid[o] = b1[o];
+    for (int c = 0; c < C; ++c) {
+        const float vm = i > 0 ? pm[(int64_t)c * L + i - 1] : 0.f;
+        const float v0 = pm[(int64_t)c * L + i];
+        const float vp = i + 1 < L ? pm[(int64_t)c * L + i + 1] : 0.f;
+        for (int o = 0; o < C; ++o) {
+            const float* ww = w1 + ((int64_t)o * C + c) * 3;
+            hid[o] = fmaf(ww[2], vp, fmaf(ww[1], v0, fmaf(ww[0], vm, hid[o])));
+        }
+    }
+    for (int o = 0; o < C; ++o) hid[o] = hid[o] > 0.f ? hid[o] : 0.f;
+    for (int o = 0; o < C; ++o) {
+        float a = b2[o];
+        for (int c = 0; c < C; ++c) a = fmaf(w2[o * C + c], hid[c], a);
+        const float att = 1.f / (1.f + expf(-a));
+        const int64_t idx = ((int64_t)b * C + o) * L + i;
+        out[idx] = m ? (x ? x[idx] : 0.f) + (m[idx] * 2.f) * (att - 0.5f) : att;
+    }
+}
+
+extern "C" int cwfa_attention_combine_f32(const float* mean, const float* w1, const float* b1, const float* w2,
+                                          const float* b2, const float* m, const float* x, float* out, int B, int C,
+                                          int64_t HW, void* stream) {
+    CWFA_REQUIRE(mean && w1 && b1 && w2 && b2 && out, CWFA_E_INVAL, "cwfa_attention_combine_f32: null pointer");
+    CWFA_REQUIRE(C > 0 && C <= CWFA_ATT_MAXC, CWFA_E_SHAPE, "cwfa_attention_combine_f32: C=%d not in 1..%d", C, CWFA_ATT_MAXC);
+    CWFA_REQUIRE(B >= 0 && HW >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_attention_combine_f32: bad shape");
+    if (B == 0 || HW == 0) return CWFA_OK;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, mean,
+                       w1, b1, w2, b2, m, x, out, C, HW);
+    CWFA_LAUNCH_CHECK("cwfa_attention_combine_f32");
+    return CWFA_OK;
+}

@@ -1,0 +1,427 @@
+"""Tensor-level wrappers over the C ABI (include/cwfa_hip.h).  PyTorch-ROCm provides device memory and the current
+HIP stream; every computation happens in libcwfa_hip.so.  Inputs must be fp32 tensors on a HIP device -- a CPU tensor
+raises (there is no CPU path in the product; the CPU restatement lives in oracle/ and is test infrastructure)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AffineStage, Chain, ConvOpts, check
+
+__all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
+           "conv2d", "conv3d_1k1", "channel_stats", "bn_fold", "maxpool", "sample_stats", "layernorm_apply",
+           "attention_combine", "scale_channels", "axpby", "stage"]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(t, name="tensor"):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: cwfa_amd runs on MI355X only -- got a {t.device} tensor (no CPU fallback exists)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def planes(t, name="tensor"):
+    """Return (tensor, batch_stride) with contiguous [H,W] planes and channel stride H*W (channel-sliced views of a
+    contiguous NCHW tensor qualify without a copy)."""
+    _dev(t, name)
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected [B,C,H,W], got {tuple(t.shape)}")
+    B, Cc, H, W = t.shape
+    ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (Cc == 1 or t.stride(1) == H * W)
+    if not ok or (B > 1 and t.stride(0) < Cc * H * W):
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else Cc * H * W)
+
+
+def _idx(perm, name="perm"):
+    if perm is None:
+        return None
+    if not perm.is_cuda or perm.dtype != torch.int64:
+        raise RuntimeError(f"{name}: index table must be an int64 tensor on the HIP device")
+    return perm if perm.is_contiguous() else perm.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ wavelets
+def haar1d(x, rev=False, lo=None, hi=None):
+    """fwd: x[B,D,H,W] -> one [B,D,H,W] tensor (lo | hi halves).  rev: that layout (or separate lo, hi) -> x."""
+    L = _lib.lib()
+    if not rev:
+        x, xbs = planes(x, "x")
+        B, D, H, W = x.shape
+        out = torch.empty((B, D, H, W), dtype=x.dtype, device=x.device)
+        h = D // 2
+        check(L.cwfa_haar1d_fwd_f32(_p(x), _p(out), C.c_void_p(out.data_ptr() + 4 * h * H * W), B, D, H * W, xbs,
+                                    D * H * W, D * H * W, _stream()), "haar1d_fwd")
+        return out
+    if lo is None:
+        x, xbs = planes(x, "x")
+        B, D, H, W = x.shape
+        h = D // 2
+        lo_p, hi_p, lbs, hbs = _p(x), C.c_void_p(x.data_ptr() + 4 * h * H * W), xbs, xbs
+        keep = (x,)
+    else:
+        lo, lbs = planes(lo, "lo")
+        hi, hbs = planes(hi, "hi")
+        B, h, H, W = lo.shape
+        D = 2 * h
+        lo_p, hi_p = _p(lo), _p(hi)
+        keep = (lo, hi)
+    out = torch.empty((B, D, H, W), dtype=torch.float32, device=keep[0].device)
+    check(L.cwfa_haar1d_inv_f32(lo_p, hi_p, _p(out), B, D, H * W, lbs, hbs, D * H * W, _stream()), "haar1d_inv")
+    return out
+
+
+def haar2d(x, rev, order_by_wavelet, fac):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    if not rev:
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, 4 * Cc, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        check(L.cwfa_haar2d_fwd_f32(_p(x), _p(out), B, Cc, H, W, int(order_by_wavelet), float(fac), _stream()),
+              "haar2d_fwd")
+        return out
+    B, C4, h, w = x.shape
+    out = torch.empty((B, C4 // 4, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    check(L.cwfa_haar2d_inv_f32(_p(x), _p(out), B, C4 // 4, 2 * h, 2 * w, int(order_by_wavelet), float(fac), _stream()),
+          "haar2d_inv")
+    return out
+
+
+def gather(x, perm, axis):
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    perm = _idx(perm)
+    B, Cc, H, W = x.shape
+    if perm.numel() != x.shape[axis]:
+        raise ValueError(f"perm of length {perm.numel()} does not match axis {axis} of {tuple(x.shape)}")
+    out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    check(L.cwfa_gather_f32(_p(x), _p(perm), _p(out), B, Cc, H, W, axis, xbs, Cc * H * W, _stream()), "gather")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ affine / chains
+def stage(s_raw=None, t=None, clamp_kind="ATAN", clamp=2.0, pre_scale=1.0, t_neg_div_sqrt2=False, perm=None, axis=1,
+          gin=False):
+    """Describe one coupling stage (see cwfa_affine_stage).  Returns (ctypes struct, keep-alive tuple)."""
+    st = AffineStage()
+    keep = []
+    if s_raw is not None:
+        s_raw, sbs = planes(s_raw, "s_raw")
+        st.s_raw, st.s_bs = s_raw.data_ptr(), sbs
+        keep.append(s_raw)
+    if t is not None:
+        t, tbs = planes(t, "t")
+        st.t, st.t_bs = t.data_ptr(), tbs
+        keep.append(t)
+    st.clamp_kind = _lib.CLAMP[clamp_kind]
+    st.clamp = float(clamp)
+    st.pre_scale = float(pre_scale)
+    st.t_neg_div_sqrt2 = int(bool(t_neg_div_sqrt2))
+    if perm is not None:
+        perm = _idx(perm)
+        st.perm = perm.data_ptr()
+        keep.append(perm)
+    st.perm_axis = int(axis)
+    st.gin = int(bool(gin))
+    return st, tuple(keep)
+
+
+def affine(x, st_keep, rev, shape=None, logdet=None, sumsq=None, out=None):
+    """y = A(gather(x)) for one stage.  x may be None (zeros) if `shape` is given.  `out` may be a channel-slice view
+    (also x itself when the stage has no gather)."""
+    L = _lib.lib()
+    st, keep = st_keep
+    if x is not None:
+        x, xbs = planes(x, "x")
+        shape = tuple(x.shape)
+        dev = x.device
+    else:
+        xbs = 0
+        dev = keep[0].device
+    B, Cc, H, W = shape
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        ybs = Cc * H * W
+    else:
+        o2, ybs = planes(out, "out")
+        if o2.data_ptr() != out.data_ptr() or tuple(out.shape) != tuple(shape):
+            raise ValueError("affine: `out` must be a [B,C,H,W] view with contiguous planes")
+    check(L.cwfa_affine_f32(_p(x), _p(out), C.byref(st), int(bool(rev)), B, Cc, H, W, xbs, ybs, _p(logdet),
+                            _p(sumsq), _stream()), "affine")
+    return out
+
+
+def channel_affine(x, scale, shift, inverse=False, perm_in=None, perm_out=None):
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    check(L.cwfa_channel_affine_f32(_p(x), _p(out), _p(scale), _p(shift), int(bool(inverse)), _p(_idx(perm_in)),
+                                    _p(_idx(perm_out)), B, Cc, H * W, xbs, Cc * H * W, _stream()), "channel_affine")
+    return out
+
+
+def _chain(stages):
+    if len(stages) > _lib.CHAIN_MAX:
+        raise ValueError(f"chain of {len(stages)} stages exceeds CWFA_CHAIN_MAX={_lib.CHAIN_MAX}")
+    ch = Chain()
+    ch.n_stages = len(stages)
+    keep = []
+    for k, (st, kp) in enumerate(stages):
+        ch.stage[k] = st
+        keep.append(kp)
+    return ch, keep
+
+
+def chain_inv(z, low, stages, logdet=None):
+    """x[B,2C,H,W] = Haar1D^-1(cat[low, A_{K-1}^-1(...A_0^-1(z))]); z may be None (= zeros)."""
+    L = _lib.lib()
+    low, lbs = planes(low, "low")
+    B, Cc, H, W = low.shape
+    zbs = 0
+    if z is not None:
+        z, zbs = planes(z, "z")
+        if tuple(z.shape) != tuple(low.shape):
+            raise ValueError(f"z {tuple(z.shape)} and low {tuple(low.shape)} differ")
+    ch, keep = _chain(stages)
+    out = torch.empty((B, 2 * Cc, H, W), dtype=torch.float32, device=low.device)
+    check(L.cwfa_chain_inv_f32(_p(z), _p(low), _p(out), C.byref(ch), B, Cc, H, W, zbs, lbs, 2 * Cc * H * W, _p(logdet),
+                               _stream()), "chain_inv")
+    return out
+
+
+def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
+    """(z, low) for x[B,2C,H,W]."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, D, H, W = x.shape
+    Cc = D // 2
+    ch, keep = _chain(stages)
+    low = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    z = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(L.cwfa_chain_fwd_f32(_p(x), _p(low), _p(z), C.byref(ch), _p(_idx(final_perm)), B, Cc, H, W, xbs, Cc * H * W,
+                               Cc * H * W, _p(logdet), _p(sumsq), _stream()), "chain_fwd")
+    return z, low
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+class PackedConv:
+    """Kernel-layout image of one filter bank (built once per weight version on the device)."""
+    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr")
+
+    def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr):
+        self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
+        self.transposed, self.version, self.src_ptr = transposed, version, src_ptr
+
+
+def pack_conv_weight(w, transposed=False):
+    """w: [Cout,Cin,k,k] (k in 1,3,7), or with transposed=True a ConvTranspose2d weight [Cin,Co,2,2]."""
+    L = _lib.lib()
+    w = _dev(w, "weight").detach().contiguous()
+    if transposed:
+        cin, co, kh, kw = w.shape
+        if (kh, kw) != (2, 2):
+            raise ValueError("only 2x2 stride-2 transposed convolutions are supported")
+        cout, ks = 4 * co, 1
+    else:
+        cout, cin, ks, kw = w.shape
+        if ks != kw:
+            raise ValueError("square kernels only")
+    n = L.cwfa_conv2d_packed_floats(cout, cin, ks)
+    if n <= 0:
+        raise ValueError(f"unsupported filter bank {tuple(w.shape)}")
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(L.cwfa_conv2d_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv2d_pack")
+    return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr())
+
+
+def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=None, in_scale=None, in_shift=None,
+           in_add=None, out=None):
+    """y = act2(act(conv(x') + bias) + residual), x' = x*in_scale[c] + in_shift[c] + in_add.  Transposed banks
+    (ConvTranspose2d k2 s2) write the pixel-shuffled [B,Co,2H,2W] output."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, Cin, H, W = x.shape
+    if Cin != pc.cin:
+        raise ValueError(f"conv2d: input has {Cin} channels, filter bank expects {pc.cin}")
+    o = ConvOpts()
+    keep = [x]
+    up = bool(pc.transposed)
+    oshape = (B, pc.cout // 4, 2 * H, 2 * W) if up else (B, pc.cout, H, W)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        ybs = oshape[1] * oshape[2] * oshape[3]
+    else:
+        if tuple(out.shape) != oshape:
+            raise ValueError(f"conv2d: out has shape {tuple(out.shape)}, expected {oshape}")
+        out_c, ybs = planes(out, "out")
+        if out_c.data_ptr() != out.data_ptr():
+            raise ValueError("conv2d: `out` must have contiguous planes")
+    if bias is not None:
+        o.bias = _dev(bias, "bias").data_ptr()
+    o.act, o.act2 = _lib.ACT[act], _lib.ACT[act2]
+    if prelu_alpha is not None:
+        o.prelu_alpha = _dev(prelu_alpha, "prelu_alpha").data_ptr()
+    elif "prelu" in (act, act2):
+        raise ValueError("conv2d: PReLU needs prelu_alpha")
+    if residual is not None:
+        residual, rbs = planes(residual, "residual")
+        if tuple(residual.shape) != oshape:
+            raise ValueError(f"conv2d: residual {tuple(residual.shape)} != output {oshape}")
+        o.residual, o.res_bs = residual.data_ptr(), rbs
+        keep.append(residual)
+    if in_scale is not None:
+        o.in_scale, o.in_shift = _dev(in_scale).data_ptr(), _dev(in_shift).data_ptr()
+        if in_scale.numel() not in (Cin, B * Cin) or in_shift.numel() != in_scale.numel():
+            raise ValueError("conv2d: in_scale / in_shift must be [Cin] or [B,Cin]")
+        o.in_affine_bs = Cin if (in_scale.numel() == B * Cin and B > 1) else 0
+    if in_add is not None:
+        in_add, abs_ = planes(in_add, "in_add")
+        if tuple(in_add.shape) != tuple(x.shape):
+            raise ValueError("conv2d: in_add shape mismatch")
+        o.in_add, o.in_add_bs = in_add.data_ptr(), abs_
+        keep.append(in_add)
+    o.upshuffle2 = int(up)
+    rec = conv_event_sink
+    if rec is not None:                    # bench.py: HIP events around selected launches, on the launch stream
+        key = (pc.ks, Cin, pc.cout, H, W, B)
+        if rec.want(key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+    check(L.cwfa_conv2d_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, pc.ks, xbs, ybs, C.byref(o),
+                            _stream()), "conv2d")
+    if rec is not None and rec.want(key):
+        e1.record()
+        rec.add(key, e0, e1)
+    return out
+
+
+conv_event_sink = None      # object with want(key)->bool and add(key, start_event, end_event); set by bench.py only
+
+
+def conv3d_1k1(x, w1, b1, alpha, w2, b2):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    B, D, H, W = x.shape
+    K = w1.shape[0]
+    out = torch.empty_like(x)
+    check(L.cwfa_conv3d_1k1_f32(_p(x), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(alpha)), _p(_dev(w2).contiguous()),
+                                _p(_dev(b2)), _p(out), B, D, H, W, K, _stream()), "conv3d_1k1")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ LRNN helpers
+def channel_stats(x):
+    """double[2*C]: per-channel (sum, sumsq) over (B,H,W)."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, Cc, H, W = x.shape
+    st = torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
+    check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
+    return st
+
+
+def bn_fold(C_, weight=None, bias=None, eps=1e-5, stats=None, count=0.0, running_mean=None, running_var=None,
+            mask_bc=None):
+    """(scale, shift) of a BatchNorm (batch or running statistics), optionally times a per-(sample,channel) mask."""
+    L = _lib.lib()
+    ref = next(t for t in (weight, stats, running_mean, mask_bc) if t is not None)
+    B = 0
+    n = C_
+    if mask_bc is not None:
+        mask_bc = _dev(mask_bc, "mask").contiguous()
+        B = mask_bc.numel() // C_
+        n = B * C_
+    scale = torch.empty(n, dtype=torch.float32, device=ref.device)
+    shift = torch.empty(n, dtype=torch.float32, device=ref.device)
+    check(L.cwfa_bn_fold_f32(_p(stats), float(count), _p(running_mean), _p(running_var), _p(weight), _p(bias),
+                             float(eps), _p(mask_bc), B, _p(scale), _p(shift), C_, _stream()), "bn_fold")
+    return scale, shift
+
+
+def maxpool(x, Ho, Wo, scale=None, shift=None, want_full=False):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, Cc, Ho, Wo), dtype=x.dtype, device=x.device)
+    full = torch.empty_like(x) if want_full else None
+    check(L.cwfa_maxpool_f32(_p(x), _p(y), _p(full), _p(scale), _p(shift), B, Cc, H, W, Ho, Wo, _stream()), "maxpool")
+    return (y, full) if want_full else y
+
+
+def sample_stats(x):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    B = x.shape[0]
+    st = torch.zeros(2 * B, dtype=torch.float64, device=x.device)
+    check(L.cwfa_sample_stats_f32(_p(x), _p(st), B, x[0].numel(), _stream()), "sample_stats")
+    return st
+
+
+def layernorm_apply(x, stats, weight, bias, eps):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    out = torch.empty_like(x)
+    check(L.cwfa_layernorm_apply_f32(_p(x), _p(stats), _p(weight), _p(bias), float(eps), _p(out), x.shape[0],
+                                     x[0].numel(), _stream()), "layernorm_apply")
+    return out
+
+
+def attention_combine(mean, w1, b1, w2, b2, m=None, x=None):
+    L = _lib.lib()
+    mean = _dev(mean, "mean").contiguous()
+    B, Cc = mean.shape[:2]
+    HW = mean[0, 0].numel()
+    out = torch.empty_like(mean)
+    m = None if m is None else _dev(m).contiguous()
+    x = None if x is None else _dev(x).contiguous()
+    check(L.cwfa_attention_combine_f32(_p(mean), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(w2).contiguous()),
+                                       _p(_dev(b2)), _p(m), _p(x), _p(out), B, Cc, HW, _stream()), "attention_combine")
+    return out
+
+
+def scale_channels(x, scale_bc):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    B, Cc = x.shape[:2]
+    out = torch.empty_like(x)
+    check(L.cwfa_scale_channels_f32(_p(x), _p(_dev(scale_bc).contiguous()), _p(out), B, Cc, x[0, 0].numel(), _stream()),
+          "scale_channels")
+    return out
+
+
+def axpby(x, a, z=None, b=0.0):
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    z = None if z is None else _dev(z).contiguous()
+    out = torch.empty_like(x)
+    check(L.cwfa_axpby_f32(_p(x), _p(z), float(a), float(b), _p(out), x.numel(), _stream()), "axpby")
+    return out
+
+
+def concat_channels(parts):
+    """torch.cat(parts, 1) through the strided plane-copy kernel (coupling_layers.py:74-87 materialise this too)."""
+    L = _lib.lib()
+    parts = [planes(t, "part") for t in parts]
+    B, _, H, W = parts[0][0].shape
+    Ct = sum(t.shape[1] for t, _ in parts)
+    out = torch.empty((B, Ct, H, W), dtype=torch.float32, device=parts[0][0].device)
+    c0 = 0
+    for t, bs in parts:
+        if t.shape[0] != B or t.shape[2:] != (H, W):
+            raise ValueError("concat_channels: shape mismatch")
+        check(L.cwfa_channel_affine_f32(_p(t), C.c_void_p(out.data_ptr() + 4 * c0 * H * W), None, None, 0, None, None, B,
+                                        t.shape[1], H * W, bs, Ct * H * W, _stream()), "concat_channels")
+        c0 += t.shape[1]
+    return out

@@ -1,0 +1,223 @@
+/*
+ * cwfa_hip.h -- C ABI of libcwfa_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * CWFA inverse (reconstruction) and forward-NLL hot path.
+ *
+ * The reference (pvjosue/CWFA) is pure Python on torch ops and has NO native boundary; each entry
+ * point below therefore names the reference *Python* op sequence (file:line, relative to the
+ * reference root) whose stock ATen kernels it replaces.  The Python host layer (cwfa_amd/) binds
+ * these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch / C++ types.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the null stream).
+ *   - every launch function ENQUEUES work on `stream` and returns immediately: 0 on success,
+ *     <0 on error (CWFA_E_*).  Nothing aborts, nothing synchronises, nothing is allocated.
+ *   - cwfa_last_error() returns a thread-local message for the last failing call.
+ *   - tensors are fp32, NCHW, innermost (H,W) plane contiguous; where a `*_bs` argument exists it
+ *     is the batch stride IN ELEMENTS, the channel stride is H*W (so channel-sliced views of a
+ *     larger tensor are passed without a copy: Split / torch.cat never materialise).
+ *   - index tables are int64 (torch.LongTensor, as the reference stores them) and are applied
+ *     bit-exactly.
+ */
+#ifndef CWFA_HIP_H
+#define CWFA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CWFA_VERSION 100
+
+enum {
+    CWFA_OK = 0,
+    CWFA_E_INVAL = -1,  /* null pointer / bad enum / negative size */
+    CWFA_E_SHAPE = -2,  /* shape not supported by the kernel */
+    CWFA_E_ALIGN = -3,  /* pointer / stride alignment */
+    CWFA_E_HIP = -4,    /* HIP runtime error at launch */
+    CWFA_E_RCCL = -5
+};
+
+/* soft-clamp of the multiplicative coupling coefficient: s = clamp * f(a)
+ * FrEIA/modules/coupling_layers.py:50-60; all_in_one_block.py:216 (TANH) */
+enum { CWFA_CLAMP_NONE = 0, CWFA_CLAMP_ATAN = 1, CWFA_CLAMP_TANH = 2, CWFA_CLAMP_SIGMOID = 3 };
+
+/* activations usable in conv epilogues */
+enum { CWFA_ACT_NONE = 0, CWFA_ACT_ELU = 1, CWFA_ACT_PRELU = 2, CWFA_ACT_GELU = 3, CWFA_ACT_RELU = 4 };
+
+int cwfa_version(void);
+const char* cwfa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Haar wavelets
+ * ---------------------------------------------------------------------------------------------- */
+
+/* HaarTransform1D.forward(rev=False) fused with Split.forward   INN_utils.py:151-161, graph_topology.py:73-80
+ * x [B,D,H,W] -> lo [B,D/2,H,W] = (x[2i]+x[2i+1])*f,  hi = (x[2i]-x[2i+1])*f,  f = fp32(1/sqrt2).
+ * lo / hi are separate views (pass out+0 and out+(D/2)*HW with the same batch stride to get the
+ * reference's single [B,D,H,W] output).  Bit-exact with the reference (same two fp32 ops). */
+int cwfa_haar1d_fwd_f32(const float* x, float* lo, float* hi, int B, int D, int64_t HW,
+                        int64_t x_bs, int64_t lo_bs, int64_t hi_bs, void* stream);
+
+/* HaarTransform1D.forward(rev=True) fused with Split.forward(rev=True)=torch.cat   INN_utils.py:157-161
+ * x[2i] = (lo[i]+hi[i])*f, x[2i+1] = (lo[i]-hi[i])*f.  hi == NULL means hi = 0 (unused by callers today). */
+int cwfa_haar1d_inv_f32(const float* lo, const float* hi, float* x, int B, int D, int64_t HW,
+                        int64_t lo_bs, int64_t hi_bs, int64_t x_bs, void* stream);
+
+/* HaarDownsampling.forward   FrEIA/modules/reshapes.py:273-300  (2x2 spatial Haar, [B,C,H,W] <-> [B,4C,H/2,W/2])
+ * fac = 0.5*rebalance (fwd) or 0.5/rebalance (rev); order_by_wavelet selects channel order j*C+c vs c*4+j. */
+int cwfa_haar2d_fwd_f32(const float* x, float* y, int B, int C, int H, int W, int order_by_wavelet, float fac,
+                        void* stream);
+int cwfa_haar2d_inv_f32(const float* y, float* x, int B, int C, int H, int W, int order_by_wavelet, float fac,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Permutations (index gathers)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y[.., i, ..] = x[.., perm[i], ..] along axis (1 = channels, 2 = rows, 3 = columns).
+ * PermuteRandom.forward fixed_transforms.py:37-41; PermuteDim.forward INN_utils.py:73-81;
+ * AllInOneBlock hard permutation all_in_one_block.py:191-196 (a 0/1 1x1 conv == channel gather). */
+int cwfa_gather_f32(const float* x, const int64_t* perm, float* y, int B, int C, int H, int W, int axis,
+                    int64_t x_bs, int64_t y_bs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Affine coupling apply (+ fused input gather, per-channel affine, log-det, sum of squares)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    const float* s_raw;   /* [B,C,H,W] pre-clamp multiplicative coefficient; NULL = no scaling (NICE)      */
+    const float* t;       /* [B,C,H,W] additive coefficient; NULL = 0                                      */
+    int64_t s_bs, t_bs;   /* batch strides (elements)                                                      */
+    int clamp_kind;       /* CWFA_CLAMP_*                                                                  */
+    float clamp;          /* alpha (2.0 default)                                                           */
+    float pre_scale;      /* multiplies s_raw and t first (AllInOneBlock `a *= 0.1`), 1.0 otherwise        */
+    int t_neg_div_sqrt2;  /* 1: t := -t / sqrt(2)  (wavelet_flow_subnetwork2D_first pass-through,
+                             networks.py:671) so the torch.cat of that subnet never materialises          */
+    const int64_t* perm;  /* optional gather applied to the INPUT of this stage: v_in[p] = v_prev[g(p)]    */
+    int perm_axis;        /* 1 / 2 / 3 (see cwfa_gather_f32); ignored when perm == NULL                    */
+    int gin;              /* 1: subtract the channel mean of s at every pixel (GIN, coupling_layers.py:355) */
+} cwfa_affine_stage;
+
+/* One coupling apply:  fwd y = exp(s)*x' + t,   rev y = (x' - t)*exp(-s),   x' = gather(x),  s = clamp*f(pre*s_raw)
+ * coupling_layers.py:209-217,281-289,492-500; all_in_one_block.py:213-225.
+ * x == NULL means x = 0 (z at temperature 0, CWFA.py:54-55).
+ * logdet (nullable): double[B], ACCUMULATED with += sum_{c,h,w} s (fwd) or -= (rev).
+ * sumsq  (nullable): double[1], ACCUMULATED with += sum y^2  (||Z||^2 of CWFA.py:970). */
+int cwfa_affine_f32(const float* x, float* y, const cwfa_affine_stage* st, int rev, int B, int C, int H, int W,
+                    int64_t x_bs, int64_t y_bs, double* logdet, double* sumsq, void* stream);
+
+/* ActNorm / AllInOneBlock global affine, per channel:   invertible_resnet.py:78-81; all_in_one_block.py:181-196
+ * mode 0: y = x*scale[c] + shift[c];   mode 1: y = (x - shift[c]) / scale[c];
+ * optional channel gather on the input (perm, applied before the affine) or on the output
+ * (perm_out: y[:, i] = v[:, perm_out[i]] of the affine result), at most one of them. */
+int cwfa_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int mode,
+                            const int64_t* perm_in, const int64_t* perm_out, int B, int C, int64_t HW,
+                            int64_t x_bs, int64_t y_bs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused flow chain for CAT-type steps (every s,t depends on the conditions only)
+ * ---------------------------------------------------------------------------------------------- */
+#define CWFA_CHAIN_MAX 8
+
+typedef struct {
+    int n_stages;
+    cwfa_affine_stage stage[CWFA_CHAIN_MAX];   /* in EXECUTION order for the requested direction */
+} cwfa_chain;
+
+/* Inverse of one whole conditional step in ONE launch:  GraphINN.forward(rev=True) over
+ * [PermuteRandom^-1, (CAT^-1, Permute^-1) x n, CAT_first^-1, Split^-1(cat), HaarTransform1D^-1]
+ * graph_inn.py:280-311 over the graph of networks.py:305-366.
+ *   v = z (NULL = 0);  for each stage: v <- A_k^-1(gather_k(v));  x = Haar1D^-1(cat[low, v])
+ * z [B,C,H,W], low [B,C,H,W] -> x [B,2C,H,W].  logdet nullable (accumulated, rev sign). */
+int cwfa_chain_inv_f32(const float* z, const float* low, float* x, const cwfa_chain* ch, int B, int C, int H, int W,
+                       int64_t z_bs, int64_t low_bs, int64_t x_bs, double* logdet, void* stream);
+
+/* Forward (NLL direction) of one whole conditional step in ONE launch:
+ *   (low, v) = Split(Haar1D(x));  for each stage: v <- A_k(gather_k(v));  z = gather_final(v)
+ * final_perm (nullable) is the trailing PermuteRandom (networks.py:353-357).
+ * logdet += sum s (per sample), sumsq += sum z^2 (CWFA.py:966-978). */
+int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cwfa_chain* ch, const int64_t* final_perm,
+                       int B, int C, int H, int W, int64_t x_bs, int64_t low_bs, int64_t z_bs,
+                       double* logdet, double* sumsq, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D convolution on fp32 MFMA (implicit GEMM, no im2col), stride 1, zero padding ks/2, groups 1
+ * replaces nn.Conv2d / F.conv2d at networks.py:212-219,488-492,537,621-638; unet.py:99-104,66
+ * ---------------------------------------------------------------------------------------------- */
+
+/* number of floats of the packed weight image for a [Cout,Cin,ks,ks] filter bank */
+int64_t cwfa_conv2d_packed_floats(int Cout, int Cin, int ks);
+/* repack torch-layout weights [Cout,Cin,ks,ks] (device) into the kernel's tiled image (device).
+ * transposed != 0: source is ConvTranspose2d layout [Cin,Cout,ks,ks] with ks==2, stride 2 (unet.py:166);
+ * the packed image is then the equivalent 1x1 conv with 4*Cout outputs ordered (dy*2+dx)*Cout+co. */
+int cwfa_conv2d_pack_f32(const float* w, float* packed, int Cout, int Cin, int ks, int transposed, void* stream);
+
+typedef struct {
+    const float* bias;        /* [Cout] nullable                                                          */
+    int act;                  /* CWFA_ACT_* applied to (acc + bias)                                       */
+    const float* prelu_alpha; /* device scalar (nn.PReLU() has ONE parameter)                             */
+    const float* residual;    /* nullable, same shape as y; added AFTER act                               */
+    int64_t res_bs;
+    int act2;                 /* CWFA_ACT_* applied after the residual add                                */
+    const float* in_scale;    /* nullable [Cin]: input is read as x*in_scale[c] + in_shift[c]             */
+    const float* in_shift;    /*   (eval-mode BatchNorm of the producer folded into the load; exact with  */
+                              /*    zero padding because padding is inserted after the affine)            */
+    int in_affine_bs;         /* 0: in_scale/in_shift are [Cin] shared by the batch; else the per-sample
+                                 stride ([B,Cin] tables: BatchNorm x dropout2d channel mask, unet.py:80,86)  */
+    const float* in_add;      /* nullable, same shape as x: added after the affine (UNet skip add)        */
+    int64_t in_add_bs;
+    int upshuffle2;           /* 1: the Cout = 4*Co outputs are written pixel-shuffled to [B,Co,2H,2W]
+                                 (ConvTranspose2d k=2 s=2 as a 1x1 conv, unet.py:166); residual/bias then
+                                 index the shuffled output ([Co])                                         */
+} cwfa_conv_opts;
+
+int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
+                    int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Condition-net 3-D part:  Conv3d(1->K,3^3,pad 1) -> PReLU -> Conv3d(K->1,3^3,pad 1), fused
+ * networks.py:221-225,239 on the [B,1,H,W,D] view of a [B,D,H,W] tensor (depth = channel axis).
+ * w1 [K,1,3,3,3] (kh,kw,kd), b1 [K], alpha scalar, w2 [1,K,3,3,3], b2 [1].  K <= 32.
+ * ---------------------------------------------------------------------------------------------- */
+int cwfa_conv3d_1k1_f32(const float* x, const float* w1, const float* b1, const float* alpha, const float* w2,
+                        const float* b2, float* y, int B, int D, int H, int W, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LRNN pieces (unet.py:72-113,161-195; networks.py:244-262,468-555)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* per-channel batch statistics for train-mode BatchNorm2d: stats[2*C] += (sum, sumsq) over (B,H,W), double */
+int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream);
+/* turn (sum,sumsq,count) or running (mean,var) into scale/shift: scale = w*rsqrt(var+eps), shift = b - mean*scale
+ * stats != NULL: batch statistics (biased variance);  else running_mean / running_var.
+ * mask_bc (nullable, [B*C]): per-(sample,channel) multiplier (F.dropout2d keep-mask / (1-p)); scale and shift are then
+ * [B*C] tables scale[b,c] = s_c*m, shift[b,c] = t_c*m; otherwise [C] (B is ignored).
+ * weight / bias NULL mean 1 / 0 (so a bare mask can be turned into an input affine). */
+int cwfa_bn_fold_f32(const double* stats, double count, const float* running_mean, const float* running_var,
+                     const float* weight, const float* bias, float eps, const float* mask_bc, int B, float* scale,
+                     float* shift, int C, void* stream);
+/* F.adaptive_max_pool2d(x, (Ho,Wo)) (unet.py:79) with an optional per-channel affine applied BEFORE the max
+ * (the producer's BatchNorm); also writes the affine result at full resolution to `full` (nullable; the skip). */
+int cwfa_maxpool_f32(const float* x, float* y, float* full, const float* scale, const float* shift, int B, int C,
+                     int H, int W, int Ho, int Wo, void* stream);
+/* per-sample statistics over (C,H,W) for nn.LayerNorm([C,H,W]): stats[2*B] += (sum, sumsq), double */
+int cwfa_sample_stats_f32(const float* x, double* stats, int B, int64_t CHW, void* stream);
+/* y = (x - mean_b) * rstd_b * w[chw] + b[chw]   networks.py:490 (eps 1e-5) */
+int cwfa_layernorm_apply_f32(const float* x, const double* stats, const float* w, const float* b, float eps,
+                             float* y, int B, int64_t CHW, void* stream);
+/* GlobalAttention (networks.py:249-262) fused with the LRNN combine (networks.py:552-554):
+ *   att = sigmoid(W2 . relu(conv1d_k3(mean over the flattened H*W sequence) ) )
+ *   out = x + m * 2 * (att - 0.5)            (m, x nullable -> out = att) */
+int cwfa_attention_combine_f32(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+                               const float* m, const float* x, float* out, int B, int C, int64_t HW, void* stream);
+/* y = x*scale[b*C+c]  (F.dropout2d channel mask / drop_path; mask generated by the caller) */
+int cwfa_scale_channels_f32(const float* x, const float* scale_bc, float* y, int B, int C, int64_t HW, void* stream);
+/* y = a*x + b*z (elementwise; z nullable) */
+int cwfa_axpby_f32(const float* x, const float* z, float a, float b, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWFA_HIP_H */

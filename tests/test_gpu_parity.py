@@ -1,0 +1,403 @@
+"""GPU (MI355X): the HIP path, called through the Python mirror -> ctypes -> C ABI, against
+  (a) the golden vectors taken from the imported reference (tests/golden), and
+  (b) the CPU oracle on fresh seeded inputs (sizes the oracle finishes in seconds),
+  (c) size-independent properties at the full 512x512x96 size (round trips, log-det antisymmetry).
+Tolerances (BASELINE.json north_star): index work bit-exact, Haar bit-exact (same two fp32 ops), fp32 outputs with
+convolutions max|d|/max|ref| <= 1e-4 and L2-relative <= 1e-4."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close, load_golden, sd_of
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).cuda()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cwfa_amd import _lib
+    _lib.lib()                        # the HIP extension must be the thing that runs
+    yield
+    torch.cuda.synchronize()
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(f"{GOLDEN}/{prefix}*.npz"))
+
+
+# ------------------------------------------------------------------------------------------------ wavelets / gathers
+def test_haar1d_golden_bit_exact():
+    from cwfa_amd.INN_utils import HaarTransform1D
+    fx = load_golden("g01_haar1d")
+    m = HaarTransform1D([tuple(fx["x"].shape[1:])])
+    (yf,), jf = m((cu(fx["x"]),), rev=False)
+    (yr,), jr = m((cu(fx["x"]),), rev=True)
+    assert torch.equal(yf.cpu(), T(fx["y_fwd"])) and torch.equal(yr.cpu(), T(fx["y_rev"]))
+    assert jf == float(fx["jac_fwd"]) and jr == float(fx["jac_rev"])
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 1, 1), (3, 6, 5, 7), (2, 10, 9, 12), (1, 48, 64, 64), (2, 4, 3, 1)])
+def test_haar1d_vs_oracle_ragged(shape):
+    from cwfa_amd import ops
+    from oracle import cwfa_oracle as O
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    for rev in (False, True):
+        assert torch.equal(ops.haar1d(x.cuda(), rev).cpu(), O.haar1d(x, rev)[0])
+    # strided (channel-sliced) input view and empty batch
+    big = torch.randn(shape[0], shape[1] + 4, shape[2], shape[3])
+    assert torch.equal(ops.haar1d(big.cuda()[:, 2:-2], False).cpu(), O.haar1d(big[:, 2:-2], False)[0])
+    assert ops.haar1d(torch.zeros(0, 4, 3, 3).cuda(), False).shape == (0, 4, 3, 3)
+
+
+def test_haar1d_full_size_roundtrip():
+    """Config-3 size: orthonormal transform -> x recovered to 1 ulp-level, energy preserved."""
+    from cwfa_amd import ops
+    x = torch.randn(1, 96, 512, 512, device="cuda")
+    y = ops.haar1d(x, False)
+    xr = ops.haar1d(y, True)
+    assert float((xr - x).abs().max()) <= 4e-7 * float(x.abs().max())
+    assert abs(float(y.double().pow(2).sum() / x.double().pow(2).sum()) - 1) < 1e-6
+    lo = y[:, :48]
+    assert torch.equal(ops.haar1d(None, True, lo=lo, hi=y[:, 48:]), xr)
+
+
+@pytest.mark.parametrize("name", names("g02_"))
+def test_haar2d(name):
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden(name)
+    kw = dict(order_by_wavelet=bool(fx["order_by_wavelet"]), rebalance=float(fx["rebalance"]))
+    m = Fm.HaarDownsampling([tuple(fx["x"].shape[1:])], **kw)
+    (yf,), jf = m((cu(fx["x"]),), rev=False)
+    (xr,), jr = m((cu(fx["z"]),), rev=True)
+    assert_close(yf, fx["y_fwd"], 2e-6)
+    assert_close(xr, fx["x_rev"], 2e-6)
+    assert abs(jf - float(fx["jac_fwd"])) < 1e-9 and abs(jr - float(fx["jac_rev"])) < 1e-9
+    up = Fm.HaarUpsampling([tuple(fx["z"].shape[1:])], **kw)
+    assert_close(up((cu(fx["z"]),))[0][0], fx["x_rev"], 2e-6)
+
+
+@pytest.mark.parametrize("axis", [1, 2, 3])
+def test_gather_bit_exact(axis):
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(axis)
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    perm = torch.randperm(x.shape[axis], generator=g)
+    assert torch.equal(ops.gather(x.cuda(), perm.cuda(), axis).cpu(), x.index_select(axis, perm))
+
+
+def test_haar2d_then_haar1d_is_the_3d_tile():
+    """north_star's '3-D 2x2x2 Haar' = FrEIA 2-D Haar composed with the depth Haar."""
+    from cwfa_amd import ops
+    from oracle import cwfa_oracle as O
+    x = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(5))
+    a = ops.haar2d(ops.haar1d(x.cuda(), False), False, True, 0.5)
+    b = O.haar2d(O.haar1d(x, False)[0], False, True, 1.0)[0]
+    assert_close(a, b, 2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+@pytest.mark.parametrize("cfg", [
+    # (B, Cin, H, W, Cout, ks)
+    (1, 3, 5, 7, 2, 3), (2, 29, 20, 33, 6, 3), (1, 8, 16, 32, 64, 3), (1, 64, 33, 70, 64, 3), (2, 64, 16, 16, 96, 3),
+    (1, 20, 17, 40, 130, 3), (1, 64, 18, 34, 64, 1), (2, 12, 9, 31, 8, 1), (1, 70, 16, 32, 200, 1),
+    (1, 6, 23, 41, 6, 7), (1, 10, 16, 38, 40, 7), (1, 256, 16, 32, 128, 3),
+])
+def test_conv2d_vs_torch_cpu(cfg):
+    from cwfa_amd import ops
+    B, Cin, H, W, Cout, ks = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    pc = ops.pack_conv_weight(w.cuda())
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
+    assert_close(ops.conv2d(x.cuda(), pc, bias=b.cuda()), ref, 2e-6, "plain")
+    y = ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="elu", residual=res.cuda(), act2="elu")
+    assert_close(y, torch.nn.functional.elu(torch.nn.functional.elu(ref) + res.double()), 3e-6, "elu+res+elu")
+    alpha = torch.tensor([0.2])
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
+    ref2 = torch.nn.functional.prelu(torch.nn.functional.conv2d(xin, w.double(), None, padding=ks // 2), alpha.double())
+    y2 = ops.conv2d(x.cuda(), pc, act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                    in_add=add.cuda())
+    assert_close(y2, ref2, 3e-6, "input affine + add + prelu")
+
+
+def test_conv_transpose_as_pixel_shuffle():
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 24, 9, 13, generator=g)
+    w = torch.randn(24, 10, 2, 2, generator=g) * 0.2
+    b = torch.randn(10, generator=g)
+    pc = ops.pack_conv_weight(w.cuda(), transposed=True)
+    ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    assert_close(ops.conv2d(x.cuda(), pc, bias=b.cuda()), ref, 2e-6)
+
+
+@pytest.mark.parametrize("cfg", [(1, 6, 9, 11, 4), (2, 8, 16, 40, 32), (1, 12, 8, 32, 32), (1, 5, 3, 3, 3)])
+def test_conv3d_1k1_vs_torch_cpu(cfg):
+    from cwfa_amd import ops
+    B, D, H, W, K = cfg
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(B, D, H, W, generator=g)
+    w1, b1 = torch.randn(K, 1, 3, 3, 3, generator=g) * 0.3, torch.randn(K, generator=g) * 0.1
+    w2, b2 = torch.randn(1, K, 3, 3, 3, generator=g) * 0.1, torch.randn(1, generator=g)
+    a = torch.tensor([0.25])
+    F = torch.nn.functional
+    v = x.double().permute(0, 2, 3, 1).unsqueeze(1)
+    v = F.conv3d(F.prelu(F.conv3d(v, w1.double(), b1.double(), padding=1), a.double()), w2.double(), b2.double(), padding=1)
+    ref = v[:, 0].permute(0, 3, 1, 2)
+    y = ops.conv3d_1k1(x.cuda(), w1.cuda(), b1.cuda(), a.cuda(), w2.cuda(), b2.cuda())
+    assert_close(y, ref, 5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ blocks
+def _block(bname, cl, fx):
+    from cwfa_amd import networks as N
+    from cwfa_amd.FrEIA import modules as Fm
+    N.networks_n_chans = 8
+    cls = {"CAT": Fm.ConditionalAffineTransform, "GLOW": Fm.GLOWCouplingBlock, "RNVP": Fm.RNVPCouplingBlock,
+           "GIN": Fm.GINCouplingBlock, "NICE": Fm.NICECouplingBlock, "ONESIDED": Fm.AffineCouplingOneSided}[bname]
+    kw = {"subnet_constructor": N.wavelet_flow_subnetwork2D}
+    if bname != "NICE":
+        kw.update(clamp=1.5, clamp_activation=cl)
+    blk = cls([tuple(fx["x"].shape[1:])], dims_c=[tuple(fx["c"].shape[1:])], **kw)
+    blk.load_state_dict(sd_of(fx))
+    return blk.eval().cuda()
+
+
+@pytest.mark.parametrize("name", names("g04_"))
+def test_coupling_blocks_golden(name):
+    fx = load_golden(name)
+    _, bname, cl = name.split("_")
+    blk = _block(bname, cl, fx)
+    x, c = cu(fx["x"]), (cu(fx["c"]),)
+    for rev, key in ((False, "fwd"), (True, "rev")):
+        (y,), j = blk((x,), c=c, rev=rev)
+        assert_close(y, fx["y_" + key], TOL, f"{name} y {key}")
+        j = j if torch.is_tensor(j) else torch.full((x.shape[0],), float(j))
+        if np.abs(fx["jac_" + key]).max() > 0:
+            assert_close(j, fx["jac_" + key], TOL, f"{name} jac {key}")
+        else:
+            assert float(j.abs().max()) == 0
+    (y,), jf = blk((x,), c=c, rev=False)
+    (xr,), jr = blk((y,), c=c, rev=True)
+    assert_close(xr, fx["x"], 1e-5, "round trip")
+
+
+@pytest.mark.parametrize("name", ["g05_ai1_gin0_cond1", "g05_ai1_gin0_cond0"])
+def test_all_in_one_golden(name):
+    from cwfa_amd import networks as N
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden(name)
+    N.networks_n_chans = 8
+    cond = fx["c"].size > 0
+    blk = Fm.AllInOneBlock([tuple(fx["x"].shape[1:])], dims_c=[tuple(fx["c"].shape[1:])] if cond else [],
+                           subnet_constructor=N.wavelet_flow_subnetwork2D)
+    blk.load_state_dict(sd_of(fx))
+    blk = blk.eval().cuda()
+    c = (cu(fx["c"]),) if cond else ()
+    for rev, key in ((False, "fwd"), (True, "rev")):
+        (y,), j = blk((cu(fx["x"]),), c=c, rev=rev)
+        assert_close(y, fx["y_" + key], TOL, f"{name} y {key}")
+        assert_close(j, fx["jac_" + key], TOL, f"{name} jac {key}")
+
+
+def test_actnorm_golden():
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden("g06_actnorm")
+    an = Fm.ActNorm([tuple(fx["x"].shape[1:])]).cuda()
+    (y,), j = an((cu(fx["x"]),), rev=False)            # data-dependent init on the first batch
+    assert_close(an.scale, fx["sd/scale"], 1e-5)
+    assert_close(an.bias, fx["sd/bias"], 1e-5)
+    assert_close(y, fx["y_fwd"], 1e-5)
+    assert_close(j, fx["jac_fwd"], 1e-5)
+    (xr,), jr = an((cu(fx["z"]),), rev=True)
+    assert_close(xr, fx["x_rev"], 1e-5)
+    assert_close(jr, fx["jac_rev"], 1e-5)
+    an2 = Fm.ActNorm([tuple(fx["x"].shape[1:])])
+    an2.load_state_dict(sd_of(fx))
+    assert an2.init_on_next_batch is False
+
+
+@pytest.mark.parametrize("name", names("g07_"))
+def test_subnets_golden(name):
+    from cwfa_amd import networks as N
+    fx = load_golden(name)
+    N.networks_n_chans = int(fx["n_ch"])
+    ctor = N.wavelet_flow_subnetwork2D_first if "first1" in name else N.wavelet_flow_subnetwork2D
+    net = ctor(int(fx["c_in"]), int(fx["c_out"]))
+    net.load_state_dict(sd_of(fx))
+    assert_close(net.cuda()(cu(fx["x"])), fx["y"], TOL, name)
+
+
+@pytest.mark.parametrize("name", names("g08_"))
+def test_omega_golden(name):
+    from cwfa_amd import networks as N
+    fx = load_golden(name)
+    net = N.cond_network(29, int(fx["c_out"]), 1, 5, [], int(fx["chans3d"]))
+    net.load_state_dict(sd_of(fx))
+    assert_close(net.eval().cuda()(cu(fx["x"]))[-1], fx["y"], TOL, name)
+
+
+# ------------------------------------------------------------------------------------------------ whole steps
+def _step(name, fx):
+    from test_host_logic import build_step
+    bt, ix = name.split("_")[2], int(name[-1])
+    _, g = build_step(bt, ix)
+    g.load_state_dict(sd_of(fx))
+    return bt, g.eval().cuda()
+
+
+@pytest.mark.parametrize("name", names("g09_"))
+def test_flow_step_golden(name):
+    fx = load_golden(name)
+    bt, g = _step(name, fx)
+    c = [cu(fx["c0"]), cu(fx["c1"])]
+    (z, low), jf = g(cu(fx["x"]), c=c)
+    assert_close(z, fx["z"], TOL, "z")
+    assert torch.equal(low.cpu(), T(fx["low"])), "low-pass half must be bit-exact"
+    assert_close(jf, fx["jac_fwd"], TOL, "jac fwd")
+    xr, jr = g([cu(fx["z"]), cu(fx["low"])], c=c, rev=True)
+    assert_close(xr, fx["x_rev"], TOL, "x_rev")
+    assert_close(jr, fx["jac_rev"], TOL, "jac rev")
+    x0, _ = g([torch.zeros_like(z), cu(fx["low"])], c=c, rev=True)
+    assert_close(x0, fx["x_rev_z0"], TOL, "x_rev from z=0")
+    if bt == "CAT":
+        # the fused plan (z=None: never read) and the node-by-node walk agree with each other and the reference
+        x0n, _ = g([None, cu(fx["low"])], c=c, rev=True)
+        assert torch.equal(x0n, x0)
+        plan, g._plan = g._plan, None
+        try:
+            (zw, loww), jw = g(cu(fx["x"]), c=c)
+            xw, jrw = g([cu(fx["z"]), cu(fx["low"])], c=c, rev=True)
+        finally:
+            g._plan = plan
+        assert_close(zw, fx["z"], TOL, "walk z")
+        assert_close(xw, fx["x_rev"], TOL, "walk x_rev")
+        assert_close(jw, fx["jac_fwd"], TOL)
+        assert_close(jrw, fx["jac_rev"], TOL)
+
+
+def _pipeline(fx):
+    from cwfa_amd import CWFA, networks as N
+    S = int(fx["S"])
+    D, H, W = fx["gt"].shape[1:]
+    conv_inn, cond_nets = [], []
+    for ix in range(S - 1):
+        cn, inns = N.conditional_wavelet_flow([D, H, W], [1, 29, H, W], N.wavelet_flow_subnetwork2D,
+                                              lambda: N.cond_network(29, D // 2 ** (ix + 1), ix + 1, S, [], 4),
+                                              n_internal_ch=8, n_down_steps=ix + 1, use_permutations=True,
+                                              block_type="CAT", n_blocks=4)
+        inns[ix].load_state_dict(sd_of(fx, f"inn{ix}/"))
+        cn.load_state_dict(sd_of(fx, f"omega{ix}/"))
+        conv_inn.append(inns[ix].eval().cuda())
+        cond_nets.append(cn.eval().cuda())
+    return CWFA, conv_inn, cond_nets, S
+
+
+def test_pipeline_golden():
+    import argparse
+    fx = load_golden("g10_pipeline")
+    CWFA, conv_inn, cond_nets, S = _pipeline(fx)
+    cond_input = (cu(fx["views"]) - float(fx["mean_imgs"])) / float(fx["std_imgs"])
+    mean_cache = [cu(fx[f"mean_cache_{n}"]) for n in range(S - 1)]
+    vols = CWFA.inverse_pass(conv_inn, cond_nets, cond_input, mean_cache, low=cu(fx["low"]), keep_all=True)
+    for i, n in enumerate(range(S - 2, -1, -1)):
+        assert_close(cond_nets[n](cond_input)[-1], fx[f"omega_{n}"], TOL, f"omega_{n}")
+        assert_close(vols[i + 1], fx[f"up_{n}"], TOL, f"up_{n}")
+    args = argparse.Namespace(INN_max_down_steps=S, force_all_steps_NF=0)
+    stats = (torch.tensor(float(fx["mean_imgs"])).cuda(), torch.tensor(float(fx["std_imgs"])).cuda())
+    losses, gt_cache, prior, logj = CWFA.evaluate_INN_forward(conv_inn, cond_nets, args, [args] * S, cu(fx["gt"]).clone(),
+                                                              cu(fx["views"]), stats)
+    for n in range(S):
+        assert torch.equal(gt_cache[n].cpu(), T(fx[f"gt_cache_{n}"]))
+    for n in range(S - 1):
+        assert abs(float(losses[n]) - fx["losses"][n]) <= TOL * abs(fx["losses"][n])
+        assert abs(float(prior[n]) - fx["prior"][n]) <= TOL * abs(fx["prior"][n])
+        assert abs(float(logj[n]) - fx["logjac"][n]) <= TOL * abs(fx["logjac"][n]) + 1e-9
+    # NLL of CWFA.py:978 through the shard-sum form, single process
+    x = cu(fx["gt"])
+    cz = [torch.zeros(x.shape[0], 8, *x.shape[2:], device="cuda")] * 2
+    nll, Z, jac = CWFA.nll_step(conv_inn[0], x, cz)
+    ref = (0.5 * torch.norm(Z[0]) ** 2 - jac.mean()) / Z[1].numel()
+    assert abs(float(nll) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+# ------------------------------------------------------------------------------------------------ LRNN
+@pytest.mark.parametrize("bias", [0, 1])
+def test_unet_golden(bias):
+    from cwfa_amd.unet import UNet
+    fx = load_golden(f"g11_unet_bias{bias}")
+    u = UNet(5, 4, depth=3, wf=3, drop_out=0, use_bias=bool(bias), skip_conn=True, up_mode="upconv", batch_norm=True)
+    u.load_state_dict(sd_of(fx))
+    u = u.cuda()
+    x = cu(fx["x"])
+    assert_close(u.eval()(x), fx["y_eval"], TOL, "eval")
+    u.train()
+    assert_close(u(x), fx["y_train"], TOL, "train (batch statistics)")
+    assert_close(u(x[:1]), fx["y_train_b1"], TOL, "train B=1")
+
+
+def test_convnext_attention_golden():
+    from cwfa_amd import networks as N
+    fx = load_golden("g11_convnext")
+    m = N.ConvNeXt(6, 10, drop_prob=0.05, size=16)
+    m.load_state_dict(sd_of(fx))
+    assert_close(m.eval().cuda()(cu(fx["x"])), fx["y"], TOL)
+    fx = load_golden("g11_attention")
+    a = N.GlobalAttention(6)
+    a.load_state_dict(sd_of(fx))
+    assert_close(a.cuda()(cu(fx["x"])), fx["y"], 1e-5)
+
+
+def test_lrnn_small_and_full_golden():
+    """Weights are regenerated from the seed (63.7 M parameters are not shipped; test_host_logic pins the RNG stream)."""
+    from cwfa_amd import networks as N
+    fs, ff = load_golden("g11_lrnn_small"), load_golden("g11_lrnn_full")
+    torch.manual_seed(int(fs["seed_init"]))
+    enc = N.Encoder(29, 6, 5, 64, True)
+    enc.net.deconv[1].drop_out = 0            # dropout2d is stochastic in the reference (unet.py:80,86)
+    gi = torch.Generator().manual_seed(int(fs["seed_input"]))
+    x_small = torch.randn(2, 29, 16, 16, generator=gi)
+    enc = enc.eval().cuda()
+    assert_close(enc(x_small.cuda())[-1], fs["y_eval"], TOL, "small, eval")
+    gi = torch.Generator().manual_seed(int(ff["seed_input"]))
+    x_full = torch.randn(1, 29, 512, 512, generator=gi)
+    mean_full = torch.randn(1, 6, 512, 512, generator=gi) * 0.1
+    gl = torch.Generator().manual_seed(int(ff["seed_ln"]))
+    with torch.no_grad():
+        for cn in enc.net.conv3d:
+            cn.m[1].weight.copy_((1 + 0.1 * torch.randn(cn.m[1].weight.shape, generator=gl)).cuda())
+            cn.m[1].bias.copy_((0.1 * torch.randn(cn.m[1].bias.shape, generator=gl)).cuda())
+    y = enc(x_full.cuda(), mean_full.cuda())[-1]
+    assert_close(y[:, :, ::23, ::29], ff["y_sub"], TOL, "full, with mean volume (subsampled)")
+    assert abs(float(y.double().sum()) - float(ff["y_sum"])) <= 1e-4 * float(ff["y_abs"])
+    assert_close(enc(x_full.cuda())[-1][:, :, ::23, ::29], ff["y_nomean_sub"], TOL, "full, no mean volume")
+
+
+def test_full_size_step_roundtrip():
+    """Config-3 finest step (C=48, 512x512): forward then inverse recovers x; log-dets are antisymmetric."""
+    from cwfa_amd import CWFA
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, with_lrnn=False)
+    g = conv_inn[0]
+    x = torch.randn(1, 96, 512, 512, device="cuda")
+    c = [0.3 * torch.randn(1, 48, 512, 512, device="cuda"), 0.1 * torch.randn(1, 48, 512, 512, device="cuda")]
+    (z, low), jf = g(x, c=c)
+    xr, jr = g([z, low], c=c, rev=True)
+    assert float((xr - x).abs().max()) <= 1e-4 * float(x.abs().max())
+    assert abs(float(jf + jr)) <= 1e-4 * abs(float(jf))

@@ -1,0 +1,123 @@
+"""CPU: host-side logic of the product -- graph construction, module/state_dict layout, permutation tables, plan lowering,
+construction-time RNG parity -- against the golden fixtures taken from the imported reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, sd_of
+
+import cwfa_amd
+from cwfa_amd import networks as N
+from cwfa_amd.FrEIA import framework as Ff
+from cwfa_amd.FrEIA import modules as Fm
+
+
+def build_step(bt, ix, D=16, H=12, W=16, S=3, n_ch=8, cond_ch=4):
+    Cn = D // 2 ** (ix + 1)
+    cond_net, inns = N.conditional_wavelet_flow(
+        [D, H, W], [1, 29, H, W], N.wavelet_flow_subnetwork2D, lambda: N.cond_network(29, Cn, ix + 1, S, [], cond_ch),
+        n_internal_ch=n_ch, n_down_steps=ix + 1, use_permutations=True, block_type=bt, n_blocks=4)
+    return cond_net, inns[ix]
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(GOLDEN + "/g09_*.npz")))
+def test_step_graph_matches_reference(name):
+    fx = load_golden(name)
+    bt, ix = name.split("_")[2], int(name[-1])
+    np.random.seed(12345)                       # tables must not depend on the incoming numpy state
+    cond_net, g = build_step(bt, ix)
+    assert [n.name for n in g.node_list] == list(fx["meta/node_names"])
+    assert [n.name for n in g.condition_nodes] == list(fx["meta/cond_node_names"])
+    assert [n.name for n in g.out_nodes] == list(fx["meta/out_node_names"])
+    assert np.array_equal(np.array(g.dims_c), fx["meta/dims_c"])
+    assert np.array_equal(np.array(g.global_out_shapes), fx["meta/global_out_shapes"])
+    ref_sd = sd_of(fx)
+    sd = g.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref_sd[k].shape) and sd[k].dtype == ref_sd[k].dtype, k
+    for i, m in enumerate(g.module_list):
+        assert type(m).__name__ == str(fx[f"meta/module_{i}"])
+        if hasattr(m, "perm") and type(m).__name__ != "HaarDownsampling":
+            assert torch.equal(m.perm, ref_sd[f"module_list.{i}.perm"]), f"perm of module {i} differs"
+            assert torch.equal(m.perm_inv, ref_sd[f"module_list.{i}.perm_inv"])
+        if f"meta/axis_{i}" in fx:
+            assert m.axis == int(fx[f"meta/axis_{i}"])
+        if type(m).__name__ == "AllInOneBlock":
+            assert torch.equal(m.w_perm, ref_sd[f"module_list.{i}.w_perm"])
+    g.load_state_dict(ref_sd)
+    # only the all-CAT step lowers to the fused chain plan
+    assert (g._plan is not None) == (bt == "CAT")
+
+
+def test_condition_net_layout_and_shared_prelu():
+    fx = load_golden("g08_omega_c8_k32")
+    net = N.cond_network(29, 8, 1, 5, [], 32)
+    ref = sd_of(fx)
+    assert list(net.state_dict().keys()) == list(ref.keys())
+    net.load_state_dict(ref)
+    other = N.cond_network(29, 4, 2, 5, [], 32)
+    assert other.subnetworks[0].relu is net.subnetworks[0].relu          # networks.py:209 default-arg aliasing
+
+
+def test_lrnn_default_init_matches_reference_rng_stream():
+    """Same torch seed -> same 63.7 M default-initialised parameters as the reference's Encoder (checksums)."""
+    fx = load_golden("g11_lrnn_small")
+    torch.manual_seed(int(fx["seed_init"]))
+    enc = N.Encoder(29, 6, 5, 64, True)
+    sd = enc.state_dict()
+    keys = [k[4:] for k in fx if k.startswith("chk/")]
+    assert list(sd.keys()) == keys
+    for k in keys:
+        v = sd[k].double()
+        got = np.array([v.sum().item(), v.abs().sum().item(), float(v.numel())])
+        assert np.allclose(got, fx["chk/" + k], rtol=1e-12, atol=1e-12), k
+
+
+def test_unet_layout():
+    from cwfa_amd.unet import UNet
+    for bias in (0, 1):
+        fx = load_golden(f"g11_unet_bias{bias}")
+        u = UNet(5, 4, depth=3, wf=3, drop_out=0, use_bias=bool(bias), skip_conn=True, up_mode="upconv", batch_norm=True)
+        assert list(u.state_dict().keys()) == list(sd_of(fx).keys())
+        u.load_state_dict(sd_of(fx))
+
+
+def test_graph_errors_and_generic_topology():
+    a = Ff.InputNode(4, 8, 8, name="in")
+    p = Ff.Node(a, Fm.PermuteRandom, {"seed": 3}, name="p")
+    s = Ff.Node(p, Fm.Split, {"section_sizes": (1, 3), "dim": 0}, name="s")
+    o0, o1 = Ff.OutputNode(s.out0, name="o0"), Ff.OutputNode(s.out1, name="o1")
+    g = Ff.GraphINN([a, p, s, o0, o1])
+    assert g._plan is None and g.global_out_shapes == [(1, 8, 8), (3, 8, 8)]
+    with pytest.raises(ValueError, match="Got 2 inputs, but expected 1"):
+        g([torch.zeros(1, 4, 8, 8)] * 2)
+    with pytest.raises(ValueError, match="Got 1 conditions, but expected 0"):
+        g(torch.zeros(1, 4, 8, 8), c=[torch.zeros(1)])
+    with pytest.raises(ValueError, match="not in the node_list"):
+        Ff.GraphINN([a, s, o0, o1])
+    with pytest.warns(DeprecationWarning):
+        Ff.ReversibleGraphNet([a, p, s, o0, o1], verbose=False)
+    seq = Ff.SequenceINN(4, 8, 8)
+    seq.append(Fm.PermuteRandom, seed=1)
+    seq.append(Fm.HaarDownsampling, order_by_wavelet=True)
+    assert seq.shapes[-1] == (16, 4, 4)
+
+
+def test_install_aliases():
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("FrEIA", "FrEIA.framework", "FrEIA.modules", "INN_utils", "networks", "unet")}
+    try:
+        cwfa_amd.install()
+        import FrEIA.framework as F2
+        import networks as n2
+        assert F2.GraphINN is Ff.GraphINN and n2.conditional_wavelet_flow is N.conditional_wavelet_flow
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
