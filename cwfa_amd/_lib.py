@@ -77,6 +77,10 @@ def lib():
             raise CwfaHipError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -m cwfa_amd.build, or "
                 f"__graft_entry__.build()).  cwfa_amd has no CPU / PyTorch fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be in the process BEFORE our library so that both bind
+        # to the SAME HIP runtime (we launch on torch's streams).  Loaded the other way round the system runtime wins
+        # and torch then finds no device.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the symbol is missing -> loud

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void haar1d_inv_kernel(const float* __restrict
 }
 
 static int haar1d_check(const char* name, const void* a, const void* b, const void* c, int B, int D, int64_t HW) {
-    CWFA_REQUIRE(a && c, CWFA_E_INVAL, "%s: null pointer", name);
     CWFA_REQUIRE(B >= 0 && D >= 0 && HW >= 0, CWFA_E_INVAL, "%s: negative size", name);
+    if (B == 0 || D == 0 || HW == 0) return CWFA_OK;        // empty tensors legitimately carry null data pointers
+    CWFA_REQUIRE(a && c, CWFA_E_INVAL, "%s: null pointer", name);
     CWFA_REQUIRE(D % 2 == 0, CWFA_E_SHAPE, "%s: depth %d is odd", name, D);
     CWFA_REQUIRE(D / 2 <= 65535 && B <= 65535, CWFA_E_SHAPE, "%s: grid too large (D/2=%d, B=%d)", name, D / 2, B);
     (void)b;
@@ -64,8 +65,8 @@ extern "C" int cwfa_haar1d_fwd_f32(const float* x, float* lo, float* hi, int B, 
                                    int64_t lo_bs, int64_t hi_bs, void* stream) {
     int rc = haar1d_check("cwfa_haar1d_fwd_f32", x, lo, hi, B, D, HW);
     if (rc) return rc;
-    CWFA_REQUIRE(lo && hi, CWFA_E_INVAL, "cwfa_haar1d_fwd_f32: null output");
     if (B == 0 || D == 0 || HW == 0) return CWFA_OK;
+    CWFA_REQUIRE(lo && hi, CWFA_E_INVAL, "cwfa_haar1d_fwd_f32: null output");
     const int h = D / 2;
     const bool v4 = HW % 4 == 0 && x_bs % 4 == 0 && lo_bs % 4 == 0 && hi_bs % 4 == 0 && cwfa_aligned16(x) &&
                     cwfa_aligned16(lo) && cwfa_aligned16(hi);
