@@ -1,0 +1,61 @@
+"""CPU, 2 processes over gloo: the batch-sharded NLL of SURVEY.md 8(e).  Each rank owns a contiguous slice of the batch,
+computes its shard sums (here with the CPU oracle standing in for the GPU kernels), one all-reduce of a float64[3]
+vector combines them, and every rank must obtain the single-process NLL of CWFA.py:978."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, sd_of
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cwfa_amd.CWFA import allreduce_nll
+        from oracle import cwfa_oracle as O
+        fx = load_golden("g09_step_CAT_k0")
+        sd = sd_of(fx)
+        axes = {i: 1 for i in range(3, 12, 2)}
+        axes.update({int(k.split("_")[-1]): int(v) for k, v in fx.items() if k.startswith("meta/axis_")})
+        x, c = torch.from_numpy(fx["x"]), [torch.from_numpy(fx["c0"]), torch.from_numpy(fx["c1"])]
+        B = x.shape[0]
+        lo, hi = rank * B // world, (rank + 1) * B // world            # contiguous batch split
+        (z, low), jac = O.flow_step(sd, x[lo:hi], [t[lo:hi] for t in c], False, axes)
+        s, j, n = O.nll_terms(z, jac)
+        terms = allreduce_nll(torch.tensor([s, j, float(n)], dtype=torch.float64))
+        nll = O.nll_from_terms(float(terms[0]), float(terms[1]), int(terms[2]), int(terms[2]) * low[0].numel())
+        # single-process reference over the whole batch (CWFA.py:970-978)
+        (zf, lowf), jf = O.flow_step(sd, x, c, False, axes)
+        ref = float((0.5 * torch.norm(zf) ** 2 - jf.mean()) / lowf.numel())
+        q.put((rank, nll, ref, int(terms[2])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_nll_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for _, nll, ref, n in res:
+        assert n == 2
+        assert abs(nll - ref) <= 1e-5 * abs(ref), (nll, ref)
+    assert res[0][1] == res[1][1], "every rank must hold the identical global NLL"
