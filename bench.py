@@ -51,7 +51,8 @@ class ConvEvents:
 
 def conv_flops(key):
     ks, cin, cout, H, W, B = key
-    return 2.0 * cout * cin * ks * ks * H * W * B
+    taps = 10 if ks == "L" else ks * ks          # "L": fused 3x3 + 1x1 sub-network layer (9 + 1 taps)
+    return 2.0 * cout * cin * taps * H * W * B
 
 
 def main():
@@ -141,7 +142,8 @@ def main():
                        "parallelism": f"replicated x{world} (independent volumes per GPU, no collective)"},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "conv2d_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+                         "kernel": ("subnet_layer_kernel" if dom[0] == "L" else "conv2d_mfma_kernel") +
+                                   " (v_mfma_f32_32x32x2_f32)",
                          "shape": dict(zip(("ks", "cin", "cout", "H", "W", "B"), dom)),
                          "flops_per_launch": conv_flops(dom), "avg_launch_ms": avg_ms, "launches_timed": n_dom,
                          "share_of_conv_time": tot[dom][0] / all_conv_ms,

@@ -50,6 +50,8 @@ SIGNATURES = {
     "cwfa_conv2d_packed_floats": (i64, [i, i, i]),
     "cwfa_conv2d_pack_f32": (i, [p, p, i, i, i, i, p]),
     "cwfa_conv2d_f32": (i, [p, p, p, i, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_subnet_pack1x1_f32": (i, [p, p, p]),
+    "cwfa_subnet_layer_f32": (i, [p, p, p, p, p, p, i, i, i, i64, i64, p]),
     "cwfa_conv3d_1k1_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
     "cwfa_channel_stats_f32": (i, [p, p, i, i, i64, i64, p]),
     "cwfa_bn_fold_f32": (i, [p, d, p, p, p, p, f, p, i, p, p, i, p]),

@@ -5,15 +5,41 @@
 //   N = pixels along W   -> MFMA cols   (B operand = input,   lane = (k = lane >> 5, pix & 31))
 //   K = (tap, ci) pairs of input channels per MFMA
 // so that an accumulator register holds 32 CONSECUTIVE PIXELS of one output channel per half-wave: NCHW stores are
-// 128-byte coalesced and the next 1x1 conv / epilogue can consume the accumulators without any lane movement.
+// 128-byte coalesced and a following 1x1 conv can take the accumulators as its B operand with no lane movement
+// (subnet_layer_kernel below does exactly that).
 //
 // Block = WM x WN waves; each wave owns MT x NT sub-tiles of 32 channels x (1 row x 32 pixels).
 // Per K-chunk of CK input channels the block stages the haloed input tile [CK][TR+ks-1][32+ks-1] and the weight
 // panel [ks*ks][CK][CT] in LDS (global loads of chunk i+1 are issued into registers before the MFMAs of chunk i),
 // every LDS operand read is a conflict-free ds_read_b32 with a compile-time immediate offset.
+//
+// Epilogues are compile-time specialised for the combinations the model uses (a runtime-switched epilogue unrolled
+// over 64 accumulators was 19k instructions / 117 KB of code and cost ~5 K-chunks of time per block); anything else
+// takes the generic (runtime) epilogue.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// tuning knobs (defaults = shipped configuration; tools/conv_tune.py builds variants with -D overrides)
+#ifndef CWFA_MINW
+#define CWFA_MINW 1
+#endif
+#ifndef CWFA_PREFETCH
+#define CWFA_PREFETCH 1
+#endif
+#ifndef CWFA_WN64
+#define CWFA_WN64 8
+#endif
+#ifndef CWFA_WM128
+#define CWFA_WM128 2
+#endif
+#ifndef CWFA_WN128
+#define CWFA_WN128 4
+#endif
+#ifndef CWFA_CK3
+#define CWFA_CK3 8
+#endif
 
 namespace {
 
@@ -42,78 +68,118 @@ struct ConvParams {
     int B, Cin, H, W, Cout, nchunks, tiles_x, tiles_y;
     int64_t x_bs, y_bs;
     cwfa_conv_opts o;
+    // fused sub-network layer only
+    const float* w1x1;      // [32 k-steps][2][64 lanes] panel of the 1x1 conv
+    const float* b1x1;
+};
+
+struct Tile {
+    int wm, wn, kh, l31, ct, b, row0, col0;
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS) void conv2d_mfma_kernel(ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;
-    float* Ws = smem + C::XS_PAD;
-
+__device__ __forceinline__ Tile make_tile(const ConvParams& p) {
+    Tile t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
+    t.wm = wave / C::WN;
+    t.wn = wave % C::WN;
+    t.kh = lane >> 5;
+    t.l31 = lane & 31;
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-    const int ct = blockIdx.y, b = blockIdx.z;
-    const int row0 = ty * C::TR, col0 = tx * C::TC;
+    t.ct = blockIdx.y;
+    t.b = blockIdx.z;
+    t.row0 = ty * C::TR;
+    t.col0 = tx * C::TC;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ main loop
+// PRO = the load-side prologue (per-channel affine and/or added tensor) is compiled in; kernels without it do not pay
+// its staging registers.
+template <class C, bool PRO>
+__device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t, float* Xs, float* Ws,
+                                              f32x16 (&acc)[C::MT][C::NT]) {
+    const int tid = threadIdx.x;
     const int64_t HW = (int64_t)p.H * p.W;
 
-    // ---- per-thread staging map for the input tile (identical for every chunk)
+    // per-thread staging map for the input tile (identical for every chunk); local channel -1 = padding / unused
     int xoff[C::XPT];
-    int xcl[C::XPT];        // local channel, -1 = not loaded
+    int xcl[C::XPT];
 #pragma unroll
     for (int i = 0; i < C::XPT; ++i) {
         const int e = tid + i * C::NTHREADS;
         const int c = e / (C::XR * C::XC), rem = e % (C::XR * C::XC);
         const int r = rem / C::XC, cc = rem % C::XC;
-        const int gr = row0 + r - C::PAD, gc = col0 + cc - C::PAD;
+        const int gr = t.row0 + r - C::PAD, gc = t.col0 + cc - C::PAD;
         const bool ok = e < C::XS && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
         xcl[i] = ok ? c : -1;
         xoff[i] = ok ? (int)(c * HW + (int64_t)gr * p.W + gc) : 0;
     }
-    const float* xb = p.x + (int64_t)b * p.x_bs;
-    const float* ab = p.o.in_add ? p.o.in_add + (int64_t)b * p.o.in_add_bs : nullptr;
-    const float* wb = p.wp + (int64_t)ct * p.nchunks * C::WS;
+    const float* xb = p.x + (int64_t)t.b * p.x_bs;
+    const float* ab = p.o.in_add ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : nullptr;
+    const float* wb = p.wp + (int64_t)t.ct * p.nchunks * C::WS;
 
-    float xr[C::XPT];
-    float4 wr[C::WPT];
+    // Staging registers.  Every global load below is UNCONDITIONAL (clamped address) and nothing waits on it here:
+    // per-element "load or zero" branches make hipcc wait vmcnt(0) element by element (measured +17 % on the UNet convs
+    // with the BatchNorm-on-load path); zeroing / the load-side affine / the skip add happen at commit time, one
+    // chunk later, when the data has long arrived.
+    constexpr int NP = PRO ? C::XPT : 1;
+    float xr[C::XPT], sr[NP], hr[NP], ar[NP];
+    f32x4 wr[C::WPT];
+    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && ab != nullptr;
+    const float* scb = has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : nullptr;
+    const float* shb = has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : nullptr;
 
     auto prefetch = [&](int chunk) {
         const int c0 = chunk * C::CK;
         const int64_t cbase = (int64_t)c0 * HW;
+        int off[C::XPT];
 #pragma unroll
-        for (int i = 0; i < C::XPT; ++i) {
-            float v = 0.f;
-            if (xcl[i] >= 0 && c0 + xcl[i] < p.Cin) {
-                v = xb[cbase + xoff[i]];
-                if (p.o.in_scale) {
-                    const int ai = b * p.o.in_affine_bs + c0 + xcl[i];
-                    v = v * p.o.in_scale[ai] + p.o.in_shift[ai];
+        for (int i = 0; i < C::XPT; ++i) off[i] = (xcl[i] >= 0 && c0 + xcl[i] < p.Cin) ? xoff[i] : 0;
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) xr[i] = xb[cbase + off[i]];
+        if constexpr (PRO) {
+            if (has_aff) {
+#pragma unroll
+                for (int i = 0; i < C::XPT; ++i) {
+                    int ci = c0 + (xcl[i] < 0 ? 0 : xcl[i]);
+                    ci = ci < p.Cin ? ci : p.Cin - 1;
+                    sr[i] = scb[ci];
+                    hr[i] = shb[ci];
                 }
-                if (ab) v += ab[cbase + xoff[i]];
             }
-            xr[i] = v;
+            if (has_add) {
+#pragma unroll
+                for (int i = 0; i < C::XPT; ++i) ar[i] = ab[cbase + off[i]];
+            }
         }
-        const float4* w4 = reinterpret_cast<const float4*>(wb + (int64_t)chunk * C::WS);
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wb + (int64_t)chunk * C::WS);
 #pragma unroll
         for (int i = 0; i < C::WPT; ++i) {
             const int e = tid + i * C::NTHREADS;
-            wr[i] = e < C::WS / 4 ? w4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wr[i] = w4[e < C::WS / 4 ? e : 0];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int chunk) {
+        const int c0 = chunk * C::CK;
 #pragma unroll
         for (int i = 0; i < C::XPT; ++i) {
             const int e = tid + i * C::NTHREADS;
-            if (e < C::XS) Xs[e] = xr[i];
+            float v = xr[i];
+            if constexpr (PRO) {
+                if (has_aff) v = v * sr[i] + hr[i];
+                if (has_add) v += ar[i];
+            }
+            if (!(xcl[i] >= 0 && c0 + xcl[i] < p.Cin)) v = 0.f;          // zero padding is inserted AFTER the affine
+            if (e < C::XS) Xs[e] = v;
         }
 #pragma unroll
         for (int i = 0; i < C::WPT; ++i) {
             const int e = tid + i * C::NTHREADS;
-            if (e < C::WS / 4) reinterpret_cast<float4*>(Ws)[e] = wr[i];
+            if (e < C::WS / 4) reinterpret_cast<f32x4*>(Ws)[e] = wr[i];
         }
     };
 
-    f32x16 acc[C::MT][C::NT];
 #pragma unroll
     for (int m = 0; m < C::MT; ++m)
 #pragma unroll
@@ -121,16 +187,22 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_mfma_kernel(ConvParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int kh = lane >> 5, l31 = lane & 31;
-    const float* wlane = Ws + kh * C::CT + (wm * C::MT) * 32 + l31;
-    const float* xlane = Xs + kh * (C::XR * C::XC) + (wn * C::NT) * C::XC + l31;
+    const float* wlane = Ws + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
+    const float* xlane = Xs + t.kh * (C::XR * C::XC) + (t.wn * C::NT) * C::XC + t.l31;
 
+#if CWFA_PREFETCH
     prefetch(0);
+#endif
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         if (chunk) __syncthreads();
-        commit();
+#if !CWFA_PREFETCH
+        prefetch(chunk);
+#endif
+        commit(chunk);
         __syncthreads();
+#if CWFA_PREFETCH
         if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
+#endif
 #pragma unroll
         for (int tap = 0; tap < C::KS * C::KS; ++tap) {
             const int dy = tap / C::KS, dx = tap % C::KS;
@@ -149,39 +221,237 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_mfma_kernel(ConvParams p) 
             }
         }
     }
+}
 
-    // ---- epilogue: bias, activation, residual, activation, (pixel-shuffled) store
-    const float alpha = (p.o.prelu_alpha && (p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU)) ? *p.o.prelu_alpha : 0.f;
-    const int col = col0 + l31;
-    const int Co = p.o.upshuffle2 ? p.Cout / 4 : p.Cout;
-    float* yb = p.y + (int64_t)b * p.y_bs;
-    const float* rb = p.o.residual ? p.o.residual + (int64_t)b * p.o.res_bs : nullptr;
-#pragma unroll
-    for (int m = 0; m < C::MT; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = ct * C::CT + (wm * C::MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co >= p.Cout) continue;
-            const int cb = p.o.upshuffle2 ? co % Co : co;
-            const float bias = p.o.bias ? p.o.bias[cb] : 0.f;
-#pragma unroll
+// scalar base + 32-bit unsigned BYTE offset: lowers to the saddr + voffset form (one VGPR per address instead of two)
+// (the empty asm pins the offset in ONE VGPR at the point of use: without it hipcc forms all 64-bit addresses of an
+//  unrolled epilogue up front -- two VGPRs each -- and spills)
+__device__ __forceinline__ float ldg_off(const float* base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg_off(float* base, unsigned byte_off, float v) {
+    asm volatile("" : "+v"(byte_off));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// channel held by accumulator register r of a 32x32 tile in lane half kh (C/D layout of the 32x32 MFMAs)
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// ------------------------------------------------------------------------------------------------ epilogues
+enum { EPI_GENERIC = 0, EPI_NONE, EPI_ELU, EPI_RES_ELU, EPI_PRELU, EPI_RES_PRELU, EPI_GELU_RES, EPI_UP, EPI_COUNT };
+
+template <int EPI>
+struct EpiTraits {
+    static constexpr int ACT1 = EPI == EPI_ELU ? CWFA_ACT_ELU : EPI == EPI_PRELU ? CWFA_ACT_PRELU
+                                : EPI == EPI_GELU_RES ? CWFA_ACT_GELU : CWFA_ACT_NONE;
+    static constexpr bool RES = EPI == EPI_RES_ELU || EPI == EPI_RES_PRELU || EPI == EPI_GELU_RES;
+    static constexpr int ACT2 = EPI == EPI_RES_ELU ? CWFA_ACT_ELU : EPI == EPI_RES_PRELU ? CWFA_ACT_PRELU : CWFA_ACT_NONE;
+    static constexpr bool UP = EPI == EPI_UP;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v, float alpha) {
+    if constexpr (ACT == CWFA_ACT_ELU) return cwfa_elu(v);
+    if constexpr (ACT == CWFA_ACT_PRELU) return v > 0.f ? v : alpha * v;
+    if constexpr (ACT == CWFA_ACT_GELU) return cwfa_gelu(v);
+    if constexpr (ACT == CWFA_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+template <class C, int EPI>
+__device__ __forceinline__ void epilogue(const ConvParams& p, const Tile& t, f32x16 (&acc)[C::MT][C::NT]) {
+    typedef EpiTraits<EPI> E;
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int col = t.col0 + t.l31;
+    float* yb = p.y + (int64_t)t.b * p.y_bs;
+    if constexpr (EPI == EPI_GENERIC) {
+        // runtime-switched path: the accumulators go through LDS so that ONE copy of the code serves all 64 of them
+        const float alpha = (p.o.prelu_alpha && (p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU)) ? *p.o.prelu_alpha : 0.f;
+        const int Co = p.o.upshuffle2 ? p.Cout / 4 : p.Cout;
+        const float* rb = p.o.residual ? p.o.residual + (int64_t)t.b * p.o.res_bs : nullptr;
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        __syncthreads();                                   // main loop done with the LDS tiles
+        float* mine = smem + (threadIdx.x >> 6) * 1024 + (threadIdx.x & 63);     // 16 floats x 64 lanes per wave
+        for (int m = 0; m < C::MT; ++m)
             for (int n = 0; n < C::NT; ++n) {
-                const int row = row0 + wn * C::NT + n;
-                if (row >= p.H || col >= p.W) continue;
-                int64_t o;
-                if (p.o.upshuffle2) {
-                    const int q = co / Co;
-                    o = (int64_t)cb * (4 * HW) + (int64_t)(2 * row + (q >> 1)) * (2 * p.W) + 2 * col + (q & 1);
-                } else {
-                    o = (int64_t)co * HW + (int64_t)row * p.W + col;
+#pragma unroll
+                for (int mm = 0; mm < C::MT; ++mm)
+#pragma unroll
+                    for (int nn = 0; nn < C::NT; ++nn)
+                        if (mm == m && nn == n) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mine[r * 64] = acc[mm][nn][r];
+                        }
+                const int row = t.row0 + t.wn * C::NT + n;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                    if (co >= p.Cout || row >= p.H || col >= p.W) continue;
+                    const int cb = p.o.upshuffle2 ? co % Co : co;
+                    int64_t o;
+                    if (p.o.upshuffle2) {
+                        const int q = co / Co;
+                        o = (int64_t)cb * (4 * HW) + (int64_t)(2 * row + (q >> 1)) * (2 * p.W) + 2 * col + (q & 1);
+                    } else {
+                        o = (int64_t)co * HW + (int64_t)row * p.W + col;
+                    }
+                    float v = cwfa_act(mine[r * 64] + (p.o.bias ? p.o.bias[cb] : 0.f), p.o.act, alpha);
+                    if (rb) v += rb[o];
+                    yb[o] = cwfa_act(v, p.o.act2, alpha);
                 }
-                float v = cwfa_act(acc[m][n][r] + bias, p.o.act, alpha);
-                if (rb) v += rb[o];
-                v = cwfa_act(v, p.o.act2, alpha);
-                yb[o] = v;
+            }
+    } else {
+        float alpha = 0.f;
+        if constexpr (E::ACT1 == CWFA_ACT_PRELU || E::ACT2 == CWFA_ACT_PRELU) alpha = *p.o.prelu_alpha;
+        const float* rb = nullptr;
+        if constexpr (E::RES) rb = p.o.residual + (int64_t)t.b * p.o.res_bs;
+        const int Co = E::UP ? p.Cout / 4 : p.Cout;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                if (co >= p.Cout) continue;
+                int cb = co, q = 0;
+                if constexpr (E::UP) {
+                    q = co / Co;
+                    cb = co - q * Co;
+                }
+                const float bias = p.o.bias ? p.o.bias[cb] : 0.f;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) {
+                    const int row = t.row0 + t.wn * C::NT + n;
+                    if (row >= p.H || col >= p.W) continue;
+                    int64_t o;
+                    if constexpr (E::UP)
+                        o = (int64_t)cb * (4 * HW) + (int64_t)(2 * row + (q >> 1)) * (2 * p.W) + 2 * col + (q & 1);
+                    else
+                        o = (int64_t)co * HW + (int64_t)row * p.W + col;
+                    float v = act_ct<E::ACT1>(acc[m][n][r] + bias, alpha);
+                    if constexpr (E::RES) v += rb[o];
+                    yb[o] = act_ct<E::ACT2>(v, alpha);
+                }
             }
         }
     }
+}
+
+template <class C, int EPI, bool PRO>
+__global__ __launch_bounds__(C::NTHREADS, CWFA_MINW) void conv2d_mfma_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Tile t = make_tile<C>(p);
+    f32x16 acc[C::MT][C::NT];
+    conv_mainloop<C, PRO>(p, t, smem, smem + C::XS_PAD, acc);
+    epilogue<C, EPI>(p, t, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ fused sub-network layer
+// One residual layer of wavelet_flow_subnetwork (networks.py:624-631,660-665) in ONE launch, C = 64 channels:
+//     y = ELU( W1x1 . ELU( conv3x3(x) + b3 ) + b1 + x )
+// The 3x3 accumulators [64 ch][64 px] of a wave are, register by register, the B operand of the 1x1 GEMM
+// (k-pair of register r = channels {32m + row(r), +4} in the two lane halves): no LDS round trip, no lane movement;
+// the A operand is a pre-permuted [32 k-steps][2 cout sub-tiles][64 lanes] image of the 1x1 weights staged in the LDS
+// region the 3x3 weight panel occupied.  The residual x (+ bias) is the initial value of the 1x1 accumulators.
+typedef Cfg<3, 8, 2, 2, 1, 8> CL;       // 64 ch x 16 rows x 32 cols, 512 threads
+
+__global__ __launch_bounds__(CL::NTHREADS, 1) void subnet_layer_kernel(ConvParams p) {
+    typedef CL C;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem + C::XS_PAD;
+    const Tile t = make_tile<C>(p);
+    f32x16 acc[2][2];
+    conv_mainloop<C, false>(p, t, smem, Ws, acc);
+
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int col = t.col0 + t.l31;
+    const bool col_ok = col < p.W;
+    const float* xb = p.x + (int64_t)t.b * p.x_bs;
+    float* yb = p.y + (int64_t)t.b * p.y_bs;
+
+    // 32-bit UNSIGNED element offsets from the (scalar) batch base: hipcc then uses the saddr + voffset addressing
+    // form; 64-bit per-element addresses cost two VGPRs each and spilled this epilogue.
+    unsigned oo[2];
+    bool ok[2];
+    const unsigned HW4 = (unsigned)HW * 4u;                    // bytes per channel plane (Cin*H*W*4 < 2^32 checked)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = t.row0 + t.wn * 2 + n;
+        ok[n] = col_ok && row < p.H;
+        oo[n] = (ok[n] ? (unsigned)(row * p.W + col) * 4u : 0u) + (unsigned)t.kh * 4u * HW4;   // + lane-half part
+    }
+    // The 1x1 GEMM runs in four quarter passes q = (mo, n): 32 chained MFMAs into ONE 32x32 accumulator each
+    // (dependent latency == issue interval for v_mfma_f32_32x32x2_f32, so a single chain keeps the pipe full).
+    // VALU work is slotted under the MFMAs: the ELU of the hidden values in the two mo=0 passes, and bias + residual +
+    // ELU + store of quarter q-1 in pass q.  Live registers: acc 64 + 2 quarters x (16 y + 16 residual) -- no spills,
+    // which unbounded hoisting of two half passes (64 y + 64 residual) did produce.
+    auto load_res = [&](int mo, int n, f32x16& res) {       // residual x + 1x1 bias, accumulator layout, clamped address
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // channel = (mo*32 + rc) + 4*kh with rc compile-time: scalar K*HW4 + one per-lane base (oo already has 4*kh)
+            const unsigned K = (unsigned)(mo * 32 + acc_row(r, 0));
+            res[r] = ldg_off(xb, K * HW4 + oo[n]) + ldg_off(p.b1x1, K * 4u + (unsigned)t.kh * 16u);
+        }
+    };
+    f32x16 yq[4], rq[4];
+    f32x16 b3v[2];                                             // 3x3 bias of this lane's 32 hidden channels
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b3v[m][r] = ldg_off(p.o.bias, (unsigned)(m * 32 + acc_row(r, 0)) * 4u + (unsigned)t.kh * 16u);
+
+    // stage the 1x1 panel (4096 floats) where the 3x3 weight panel was
+    __syncthreads();
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.w1x1);
+        f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+        for (int e = threadIdx.x; e < 1024; e += C::NTHREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    const float* wl = Ws + (threadIdx.x & 63);
+
+    // Every k-step is fenced for the instruction scheduler (hipcc otherwise hoists all loads of all passes to the top
+    // and spills); the hardware still overlaps: the MFMA of step j executes while the VALU work of step j+1 issues.
+    // The A operand of step j+1 is read from LDS during step j.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mo = q >> 1, n = q & 1;
+        load_res(mo, n, rq[q]);                                    // consumed during pass q+1 (or the tail)
+        float a_next = wl[(0 * 2 + mo) * 64];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = m * 16 + r;
+                const float a = a_next;
+                if (j + 1 < 32) a_next = wl[((j + 1) * 2 + mo) * 64];
+                if (mo == 0) acc[m][n][r] = cwfa_elu(acc[m][n][r] + b3v[m][r]);
+                if (j == 0) {       // first k-step: literal zero accumulator input (no zero-initialised registers)
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][n][r], zero, 0, 0, 0);
+                } else {
+                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][n][r], yq[q], 0, 0, 0);
+                }
+                if (q > 0 && (j & 1)) {                                 // element j/2 of the previous quarter
+                    const int pq = q > 0 ? q - 1 : 0, pmo = pq >> 1, pn = pq & 1, rr = j >> 1;
+                    const unsigned K = (unsigned)(pmo * 32 + acc_row(rr, 0));
+                    if (ok[pn]) stg_off(yb, K * HW4 + oo[pn], cwfa_elu(yq[pq][rr] + rq[pq][rr]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                      // tail: the last quarter (mo = 1, n = 1)
+        const unsigned K = (unsigned)(32 + acc_row(r, 0));
+        if (ok[1]) stg_off(yb, K * HW4 + oo[1], cwfa_elu(yq[3][r] + rq[3][r]));
+    }
+}
+
+// panel[(m*16 + r)*2 + mo][lane] = W[32*mo + (lane & 31)][32*m + row(r, lane >> 5)]      (W: [64][64] 1x1 weights)
+__global__ __launch_bounds__(256) void pack1x1_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4096) return;
+    const int lane = i & 63, mo = (i >> 6) & 1, kr = i >> 7, m = kr >> 4, r = kr & 15;
+    out[i] = w[(32 * mo + (lane & 31)) * 64 + 32 * m + acc_row(r, lane >> 5)];
 }
 
 // ---- weight repack: torch [Cout][Cin][ks][ks] -> [cout tile][chunk][tap][ck][CT]   (zeros beyond Cout / Cin)
@@ -209,12 +479,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 }
 
 // ---- configuration table.  One entry per (ks, Cout class); pack and launch MUST agree, hence one selector.
-typedef Cfg<3, 8, 1, 4, 1, 4> C3_32;      // Cout <= 32 : 32 ch x 16 rows x 32 cols, 256 threads
-typedef Cfg<3, 8, 2, 2, 1, 8> C3_64;      // Cout <= 64 : 64 ch x 16 rows x 32 cols, 512 threads
-typedef Cfg<3, 8, 2, 2, 2, 4> C3_128;     // Cout  > 64 : 128 ch x 8 rows x 32 cols, 512 threads
+typedef Cfg<3, CWFA_CK3, 1, 4, 1, 4> C3_32;                        // Cout <= 32 : 32 ch x 16 rows x 32 cols
+typedef Cfg<3, CWFA_CK3, 2, 2, 1, CWFA_WN64> C3_64;                // Cout <= 64 : 64 ch x 2*WN rows x 32 cols
+typedef Cfg<3, CWFA_CK3, 2, 2, CWFA_WM128, CWFA_WN128> C3_128;     // Cout  > 64 : 64*WM ch x 2*WN rows x 32 cols
 typedef Cfg<1, 16, 1, 4, 1, 4> C1_32;
-typedef Cfg<1, 16, 2, 2, 1, 8> C1_64;
-typedef Cfg<1, 16, 2, 2, 2, 4> C1_128;
+typedef Cfg<1, 16, 2, 2, 1, CWFA_WN64> C1_64;
+typedef Cfg<1, 16, 2, 2, CWFA_WM128, CWFA_WN128> C1_128;
 typedef Cfg<7, 4, 1, 4, 1, 4> C7_32;
 typedef Cfg<7, 4, 2, 2, 1, 8> C7_64;
 
@@ -230,28 +500,94 @@ Sel select_cfg(int ks, int Cout) {
     return Sel{-1, 0, 0};
 }
 
+int classify_epilogue(const cwfa_conv_opts& o) {
+    const bool res = o.residual != nullptr;
+    if (o.upshuffle2) return (!res && o.act == CWFA_ACT_NONE && o.act2 == CWFA_ACT_NONE) ? EPI_UP : EPI_GENERIC;
+    if (!res && o.act2 == CWFA_ACT_NONE) {
+        if (o.act == CWFA_ACT_NONE) return EPI_NONE;
+        if (o.act == CWFA_ACT_ELU) return EPI_ELU;
+        if (o.act == CWFA_ACT_PRELU) return EPI_PRELU;
+    }
+    if (res && o.act == CWFA_ACT_NONE && o.act2 == CWFA_ACT_ELU) return EPI_RES_ELU;
+    if (res && o.act == CWFA_ACT_NONE && o.act2 == CWFA_ACT_PRELU) return EPI_RES_PRELU;
+    if (res && o.act == CWFA_ACT_GELU && o.act2 == CWFA_ACT_NONE) return EPI_GELU_RES;
+    return EPI_GENERIC;
+}
+
 template <class C>
-int launch(const ConvParams& p0, hipStream_t stream) {
-    ConvParams p = p0;
+int prepare(ConvParams& p, dim3& grid) {
     p.tiles_x = (p.W + C::TC - 1) / C::TC;
     p.tiles_y = (p.H + C::TR - 1) / C::TR;
     p.nchunks = (p.Cin + C::CK - 1) / C::CK;
     const int ctiles = (p.Cout + C::CT - 1) / C::CT;
+    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
+                 "cwfa_conv2d_f32: grid too large");
+    grid = dim3((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B);
+    return CWFA_OK;
+}
+
+template <class C, int EPI, bool PRO>
+int launch_epi(ConvParams p, hipStream_t stream) {
+    dim3 grid;
+    int rc = prepare<C>(p, grid);
+    if (rc) return rc;
+    // the generic epilogue stages accumulators through 4 KB of LDS per wave
+    constexpr int LDS = EPI == EPI_GENERIC && C::LDS_BYTES < C::NTHREADS * 64 ? C::NTHREADS * 64 : C::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<C, EPI, PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
-            cwfa_set_error("cwfa_conv2d_f32: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            cwfa_set_error("cwfa_conv2d_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
             return CWFA_E_HIP;
         }
         attr_set = true;
     }
-    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
-                 "cwfa_conv2d_f32: grid too large");
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B);
-    hipLaunchKernelGGL(conv2d_mfma_kernel<C>, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<C, EPI, PRO>), grid, dim3(C::NTHREADS), LDS, stream, p);
     CWFA_LAUNCH_CHECK("cwfa_conv2d_f32");
+    return CWFA_OK;
+}
+
+// the (config, epilogue, prologue) triples the model uses get a specialised kernel; everything else is generic
+template <class C, unsigned ALLOWED, bool PRO>
+int launch_sel(const ConvParams& p, int epi, hipStream_t st) {
+    if (!(ALLOWED & (1u << epi))) epi = EPI_GENERIC;
+    switch (epi) {
+        case EPI_NONE: if constexpr (ALLOWED & (1u << EPI_NONE)) return launch_epi<C, EPI_NONE, PRO>(p, st); break;
+        case EPI_ELU: if constexpr (ALLOWED & (1u << EPI_ELU)) return launch_epi<C, EPI_ELU, PRO>(p, st); break;
+        case EPI_RES_ELU: if constexpr (ALLOWED & (1u << EPI_RES_ELU)) return launch_epi<C, EPI_RES_ELU, PRO>(p, st); break;
+        case EPI_PRELU: if constexpr (ALLOWED & (1u << EPI_PRELU)) return launch_epi<C, EPI_PRELU, PRO>(p, st); break;
+        case EPI_RES_PRELU: if constexpr (ALLOWED & (1u << EPI_RES_PRELU)) return launch_epi<C, EPI_RES_PRELU, PRO>(p, st); break;
+        case EPI_GELU_RES: if constexpr (ALLOWED & (1u << EPI_GELU_RES)) return launch_epi<C, EPI_GELU_RES, PRO>(p, st); break;
+        case EPI_UP: if constexpr (ALLOWED & (1u << EPI_UP)) return launch_epi<C, EPI_UP, PRO>(p, st); break;
+        default: break;
+    }
+    return launch_epi<C, EPI_GENERIC, PRO>(p, st);
+}
+
+// ALLOWED: specialised epilogues without a load-side prologue; ALLOWED_PRO: with one (BatchNorm-on-load / skip add)
+template <class C, unsigned ALLOWED, unsigned ALLOWED_PRO>
+int launch(const ConvParams& p, int epi, hipStream_t st) {
+    if (p.o.in_scale || p.o.in_add) return launch_sel<C, ALLOWED_PRO, true>(p, epi, st);
+    return launch_sel<C, ALLOWED, false>(p, epi, st);
+}
+
+int fill_params(ConvParams& p, const char* name, const float* x, const float* w_packed, float* y, int B, int Cin, int H,
+                int W, int Cout, int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts) {
+    CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "%s: bad size", name);
+    if (B == 0 || H == 0 || W == 0) return 1;                                    // empty: nothing to do
+    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "%s: null pointer", name);
+    CWFA_REQUIRE((int64_t)Cin * H * W < (1ll << 30) && (int64_t)Cout * H * W * (p.o.upshuffle2 ? 1 : 1) < (1ll << 30), CWFA_E_SHAPE, "%s: C*H*W exceeds the 32-bit byte offsets of a tile (2^30 elements per image)", name);
+    CWFA_REQUIRE(cwfa_aligned16(w_packed), CWFA_E_ALIGN, "%s: packed weights must be 16-byte aligned", name);
+    p.x = x; p.wp = w_packed; p.y = y;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.x_bs = x_bs; p.y_bs = y_bs;
+    if (opts) p.o = *opts;
+    CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "%s: in_scale without in_shift", name);
+    CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
+                 "%s: bad activation", name);
+    CWFA_REQUIRE(!((p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU) && !p.o.prelu_alpha), CWFA_E_INVAL,
+                 "%s: PReLU without prelu_alpha", name);
     return CWFA_OK;
 }
 
@@ -280,31 +616,52 @@ extern "C" int cwfa_conv2d_pack_f32(const float* w, float* packed, int Cout, int
 
 extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
-    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "cwfa_conv2d_f32: null pointer");
-    CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_conv2d_f32: bad size");
-    CWFA_REQUIRE((int64_t)Cin * H * W < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv2d_f32: Cin*H*W exceeds 32-bit tile offsets");
     const Sel s = select_cfg(ks, Cout);
     CWFA_REQUIRE(s.id >= 0, CWFA_E_SHAPE, "cwfa_conv2d_f32: kernel size %d not in {1,3,7}", ks);
-    CWFA_REQUIRE(cwfa_aligned16(w_packed), CWFA_E_ALIGN, "cwfa_conv2d_f32: packed weights must be 16-byte aligned");
-    if (B == 0 || H == 0 || W == 0) return CWFA_OK;
     ConvParams p{};
-    p.x = x; p.wp = w_packed; p.y = y;
-    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
-    p.x_bs = x_bs; p.y_bs = y_bs;
-    if (opts) p.o = *opts;
+    int rc = fill_params(p, "cwfa_conv2d_f32", x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, opts);
+    if (rc) return rc < 0 ? rc : CWFA_OK;
     CWFA_REQUIRE(!p.o.upshuffle2 || (ks == 1 && Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv2d_f32: upshuffle2 needs ks=1, Cout=4*Co");
-    CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "cwfa_conv2d_f32: in_scale without in_shift");
-    CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
-                 "cwfa_conv2d_f32: bad activation");
+    const int epi = classify_epilogue(p.o);
     hipStream_t st = (hipStream_t)stream;
+    constexpr unsigned N = 1u << EPI_NONE, E = 1u << EPI_ELU, RE = 1u << EPI_RES_ELU, P = 1u << EPI_PRELU,
+                       RP = 1u << EPI_RES_PRELU, G = 1u << EPI_GELU_RES, U = 1u << EPI_UP;
     switch (s.id) {
-        case 0: return launch<C3_32>(p, st);
-        case 1: return launch<C3_64>(p, st);
-        case 2: return launch<C3_128>(p, st);
-        case 3: return launch<C1_32>(p, st);
-        case 4: return launch<C1_64>(p, st);
-        case 5: return launch<C1_128>(p, st);
-        case 6: return launch<C7_32>(p, st);
-        default: return launch<C7_64>(p, st);
+        case 0: return launch<C3_32, N | P | RP, 0>(p, epi, st);
+        case 1: return launch<C3_64, N | E | P | RP, 0>(p, epi, st);
+        case 2: return launch<C3_128, N | P, P>(p, epi, st);
+        case 3: return launch<C1_32, N | P | G, P>(p, epi, st);
+        case 4: return launch<C1_64, N | RE | G, 0>(p, epi, st);
+        case 5: return launch<C1_128, N | U, U>(p, epi, st);
+        case 6: return launch<C7_32, N, 0>(p, epi, st);
+        default: return launch<C7_64, N, 0>(p, epi, st);
     }
+}
+
+extern "C" int cwfa_subnet_pack1x1_f32(const float* w, float* panel, void* stream) {
+    CWFA_REQUIRE(w && panel, CWFA_E_INVAL, "cwfa_subnet_pack1x1_f32: null pointer");
+    hipLaunchKernelGGL(pack1x1_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, panel);
+    CWFA_LAUNCH_CHECK("cwfa_subnet_pack1x1_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_subnet_layer_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel,
+                                     const float* b1, float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream) {
+    ConvParams p{};
+    cwfa_conv_opts o{};
+    o.bias = b3;
+    int rc = fill_params(p, "cwfa_subnet_layer_f32", x, w3_packed, y, B, 64, H, W, 64, x_bs, y_bs, &o);
+    if (rc) return rc < 0 ? rc : CWFA_OK;
+    CWFA_REQUIRE(b3 && w1_panel && b1, CWFA_E_INVAL, "cwfa_subnet_layer_f32: null pointer");
+    CWFA_REQUIRE(x != y, CWFA_E_INVAL, "cwfa_subnet_layer_f32: in-place not supported (3x3 halo)");
+    CWFA_REQUIRE(cwfa_aligned16(w1_panel), CWFA_E_ALIGN, "cwfa_subnet_layer_f32: 1x1 panel must be 16-byte aligned");
+    static_assert(CL::CT == 64 && C3_64::CT == 64 && C3_64::CK == CL::CK, "fused layer shares the 3x3 64-channel packing");
+    p.w1x1 = w1_panel;
+    p.b1x1 = b1;
+    dim3 grid;
+    rc = prepare<CL>(p, grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(subnet_layer_kernel, grid, dim3(CL::NTHREADS), CL::LDS_BYTES, (hipStream_t)stream, p);
+    CWFA_LAUNCH_CHECK("cwfa_subnet_layer_f32");
+    return CWFA_OK;
 }

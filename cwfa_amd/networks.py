@@ -106,6 +106,7 @@ class wavelet_flow_subnetwork(nn.Module):
         self.init_blocks(nn.Conv3d, nn.BatchNorm3d)      # as the reference: consumes the RNG, then gets replaced
         self.normal = True
         self._packed = _Packed()
+        self._panels = {}
 
     def init_blocks(self, conv_type, bn=nn.BatchNorm2d, use_bias=True):
         self.conv_type = conv_type
@@ -130,10 +131,22 @@ class wavelet_flow_subnetwork(nn.Module):
             raise NotImplementedError("3-D sub-networks are not used by CWFA (every graph uses the 2-D subclasses)")
         P = self._packed.get
         b = ops.conv2d(u, P(conv_in), bias=conv_in.bias)
+        fused = self.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None
+                                        for blk in (self.block2, self.block4, self.block6))
         for blk in (self.block2, self.block4, self.block6):
+            if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
+                b = ops.subnet_layer(b, P(blk[0]), blk[0].bias, self._panel(blk[2]), blk[2].bias)
+                continue
             h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")
             b = ops.conv2d(h, P(blk[2]), bias=blk[2].bias, residual=b, act2="elu")   # ELU = block3 / block5 / block7x[0]
         return ops.conv2d(b, P(conv_out), bias=conv_out.bias, out=out)
+
+    def _panel(self, conv):
+        w = conv.weight
+        pc = self._panels.get(id(conv))
+        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr():
+            pc = self._panels[id(conv)] = ops.pack_1x1_panel(w)
+        return pc
 
     def affine_parts(self, parts, n_s):
         """(s_raw, t, t_neg_div_sqrt2) for a coupling block, without materialising any concatenation."""

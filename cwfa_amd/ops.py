@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv3d_1k1", "channel_stats", "bn_fold", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "pack_1x1_panel", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -308,6 +308,39 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
 
 
 conv_event_sink = None      # object with want(key)->bool and add(key, start_event, end_event); set by bench.py only
+
+
+def pack_1x1_panel(w):
+    """[64,64,1,1] filter -> the lane-ordered A-operand image the fused sub-network layer consumes."""
+    L = _lib.lib()
+    w = _dev(w, "weight").detach().contiguous()
+    if tuple(w.shape) != (64, 64, 1, 1):
+        raise ValueError("pack_1x1_panel: the fused layer kernel is specialised for 64 channels")
+    panel = torch.empty(4096, dtype=torch.float32, device=w.device)
+    check(L.cwfa_subnet_pack1x1_f32(_p(w), _p(panel), _stream()), "subnet_pack1x1")
+    return PackedConv(panel, 64, 64, 1, False, w._version, w.data_ptr())
+
+
+def subnet_layer(x, pc3, b3, panel1, b1):
+    """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, Cc, H, W = x.shape
+    if Cc != 64 or pc3.cin != 64 or pc3.cout != 64 or pc3.ks != 3:
+        raise ValueError("subnet_layer: 64-channel 3x3 layers only")
+    out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+    rec = conv_event_sink
+    if rec is not None:
+        key = ("L", 64, 64, H, W, B)
+        if rec.want(key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+    check(L.cwfa_subnet_layer_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
+                                  xbs, 64 * H * W, _stream()), "subnet_layer")
+    if rec is not None and rec.want(key):
+        e1.record()
+        rec.add(key, e0, e1)
+    return out
 
 
 def conv3d_1k1(x, w1, b1, alpha, w2, b2):

@@ -176,6 +176,15 @@ typedef struct {
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                     int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
 
+/* One residual layer of the coupling sub-network (networks.py:624-631,660-665) fused into ONE launch, 64 channels:
+ *     y = ELU( conv1x1( ELU( conv3x3(x) + b3 ) ) + b1 + x )
+ * The 3x3 accumulators are consumed in registers as the B operand of the 1x1 MFMAs; the hidden map never exists in
+ * memory.  w3_packed: cwfa_conv2d_pack_f32 image of the [64,64,3,3] filter; w1_panel: cwfa_subnet_pack1x1_f32 image
+ * (4096 floats) of the [64,64,1,1] filter. */
+int cwfa_subnet_pack1x1_f32(const float* w, float* panel, void* stream);
+int cwfa_subnet_layer_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1,
+                          float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Condition-net 3-D part:  Conv3d(1->K,3^3,pad 1) -> PReLU -> Conv3d(K->1,3^3,pad 1), fused
  * networks.py:221-225,239 on the [B,1,H,W,D] view of a [B,D,H,W] tensor (depth = channel axis).

@@ -135,6 +135,39 @@ def test_conv2d_vs_torch_cpu(cfg):
     assert_close(y2, ref2, 3e-6, "input affine + add + prelu")
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 19, 45), (1, 5, 7), (1, 64, 64)])
+def test_subnet_layer_fused_vs_torch_cpu(shape):
+    """y = ELU(conv1x1(ELU(conv3x3(x)+b3)) + b1 + x) in one launch (networks.py:624-631,660-665), ragged tiles."""
+    from cwfa_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w3, b3 = torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g) * 0.1
+    w1, b1 = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1
+    F = torch.nn.functional
+    xd = x.double()
+    ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
+    y = ops.subnet_layer(x.cuda(), ops.pack_conv_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()), b1.cuda())
+    assert_close(y, ref, 3e-6)
+    # the unfused two-launch form agrees too
+    h = ops.conv2d(x.cuda(), ops.pack_conv_weight(w3.cuda()), bias=b3.cuda(), act="elu")
+    y2 = ops.conv2d(h, ops.pack_conv_weight(w1.cuda()), bias=b1.cuda(), residual=x.cuda(), act2="elu")
+    assert_close(y2, ref, 3e-6)
+
+
+def test_conv2d_generic_epilogue_combo():
+    """A combination without a specialised epilogue (GELU -> +residual -> ReLU) takes the runtime path."""
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 10, 13, 37, generator=g)
+    w, b = torch.randn(40, 10, 3, 3, generator=g) * 0.1, torch.randn(40, generator=g)
+    res = torch.randn(2, 40, 13, 37, generator=g)
+    F = torch.nn.functional
+    ref = F.relu(F.gelu(F.conv2d(x.double(), w.double(), b.double(), padding=1)) + res.double())
+    y = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), bias=b.cuda(), act="gelu", residual=res.cuda(), act2="relu")
+    assert_close(y, ref, 3e-6)
+
+
 def test_conv_transpose_as_pixel_shuffle():
     from cwfa_amd import ops
     g = torch.Generator().manual_seed(3)
