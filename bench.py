@@ -151,6 +151,7 @@ def main():
             "reference_readme": {"volumes_per_s": 6.25, "note": "README.md:29, unstated CUDA GPU, fp16 autocast; not "
                                  "this fp32 metric, hence vs_baseline is null"},
         }
+        res["roofline"]["traffic"] = pmc_traffic(res["roofline"]["kernel"], dom)
         res["roofline_dwt"] = dwt_roofline(ops, a, dev)
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
             res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
@@ -159,6 +160,23 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def pmc_traffic(kernel, dom):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    cannot be collected from inside this process; profiles/*_pmc_traffic.json holds the latest separate-pass numbers,
+    taken on the same shape).  None if no matching record."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files or dom[3:5] != (512, 512):
+        return None
+    rec = json.load(open(files[-1]))["kernels"]
+    name = kernel.split(" ")[0]
+    for k, v in rec.items():
+        if k.startswith(name) and (name != "conv2d_mfma_kernel" or "true" in k):
+            return {"bytes": (v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0, "source": os.path.basename(files[-1]),
+                    "algorithmic_bytes": 2 * 4.0 * dom[1] * dom[3] * dom[4] * dom[5]}
+    return None
 
 
 def dwt_roofline(ops, a, dev, reps=20):
