@@ -38,6 +38,7 @@ i, i64, f, d, p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
 SIGNATURES = {
     "cwfa_version": (i, []),
     "cwfa_last_error": (C.c_char_p, []),
+    "cwfa_set_option": (i, [C.c_char_p, i]),
     "cwfa_haar1d_fwd_f32": (i, [p, p, p, i, i, i64, i64, i64, i64, p]),
     "cwfa_haar1d_inv_f32": (i, [p, p, p, i, i, i64, i64, i64, i64, p]),
     "cwfa_haar2d_fwd_f32": (i, [p, p, i, i, i, i, i, f, p]),

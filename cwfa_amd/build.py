@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcwfa_hip.so")
-SOURCES = ["elementwise.hip", "conv2d.hip", "conv3d.hip", "lrnn_ops.hip"]
+SOURCES = ["elementwise.hip", "conv2d.hip", "conv_wino.hip", "conv3d.hip", "lrnn_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
@@ -20,7 +20,8 @@ def _newer(src, dst):
 
 
 def build_all(force=False, verbose=False):
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "cwfa_hip.h"), os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(INCLUDE, "cwfa_hip.h"),
+            os.path.abspath(__file__)]
     objs, jobs = [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))

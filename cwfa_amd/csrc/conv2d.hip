@@ -16,7 +16,9 @@
 // Epilogues are compile-time specialised for the combinations the model uses (a runtime-switched epilogue unrolled
 // over 64 accumulators was 19k instructions / 117 KB of code and cost ~5 K-chunks of time per block); anything else
 // takes the generic (runtime) epilogue.
-#include "common.h"
+#include "conv_internal.h"
+
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -593,9 +595,22 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
 
 }  // namespace
 
+int g_cwfa_wino_min_cout = 65;      // TODO(33 once the Winograd fused layer is in)
+
+extern "C" int cwfa_set_option(const char* name, int value) {
+    CWFA_REQUIRE(name, CWFA_E_INVAL, "cwfa_set_option: null name");
+    if (strcmp(name, "winograd_min_cout") == 0) {
+        g_cwfa_wino_min_cout = value;
+        return CWFA_OK;
+    }
+    cwfa_set_error("cwfa_set_option: unknown option '%s'", name);
+    return CWFA_E_INVAL;
+}
+
 extern "C" int64_t cwfa_conv2d_packed_floats(int Cout, int Cin, int ks) {
     const Sel s = select_cfg(ks, Cout);
     if (s.id < 0 || Cout <= 0 || Cin <= 0) return -1;
+    if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_packed_floats(Cout, Cin);
     const int64_t ctiles = (Cout + s.CT - 1) / s.CT, nchunks = (Cin + s.CK - 1) / s.CK;
     return ctiles * nchunks * ks * ks * s.CK * s.CT;
 }
@@ -606,6 +621,7 @@ extern "C" int cwfa_conv2d_pack_f32(const float* w, float* packed, int Cout, int
                  "cwfa_conv2d_pack_f32: transposed source needs ks=1 (2x2 stride-2 deconv as 1x1) and Cout = 4*Co");
     const int64_t total = cwfa_conv2d_packed_floats(Cout, Cin, ks);
     CWFA_REQUIRE(total > 0, CWFA_E_SHAPE, "cwfa_conv2d_pack_f32: unsupported filter %dx%d, Cout=%d, Cin=%d", ks, ks, Cout, Cin);
+    if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_pack(w, packed, Cout, Cin, (hipStream_t)stream);
     const Sel s = select_cfg(ks, Cout);
     const int nchunks = (Cin + s.CK - 1) / s.CK;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cout,
@@ -624,6 +640,7 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
     CWFA_REQUIRE(!p.o.upshuffle2 || (ks == 1 && Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv2d_f32: upshuffle2 needs ks=1, Cout=4*Co");
     const int epi = classify_epilogue(p.o);
     hipStream_t st = (hipStream_t)stream;
+    if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_conv(x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, p.o, st);
     constexpr unsigned N = 1u << EPI_NONE, E = 1u << EPI_ELU, RE = 1u << EPI_RES_ELU, P = 1u << EPI_PRELU,
                        RP = 1u << EPI_RES_PRELU, G = 1u << EPI_GELU_RES, U = 1u << EPI_UP;
     switch (s.id) {
@@ -655,6 +672,8 @@ extern "C" int cwfa_subnet_layer_f32(const float* x, const float* w3_packed, con
     CWFA_REQUIRE(b3 && w1_panel && b1, CWFA_E_INVAL, "cwfa_subnet_layer_f32: null pointer");
     CWFA_REQUIRE(x != y, CWFA_E_INVAL, "cwfa_subnet_layer_f32: in-place not supported (3x3 halo)");
     CWFA_REQUIRE(cwfa_aligned16(w1_panel), CWFA_E_ALIGN, "cwfa_subnet_layer_f32: 1x1 panel must be 16-byte aligned");
+    if (cwfa_wino_selected(3, 64))      // the 3x3 weights were packed in Winograd form
+        return cwfa_wino_layer(x, w3_packed, b3, w1_panel, b1, y, B, H, W, x_bs, y_bs, (hipStream_t)stream);
     static_assert(CL::CT == 64 && C3_64::CT == 64 && C3_64::CK == CL::CK, "fused layer shares the 3x3 64-channel packing");
     p.w1x1 = w1_panel;
     p.b1x1 = b1;

@@ -1,0 +1,17 @@
+// Internal (non-ABI) interface between conv2d.hip (dispatch + direct kernels) and conv_wino.hip (Winograd kernels).
+#pragma once
+#include "common.h"
+
+// 3x3 convolutions with more than 32 output channels run the 1-D Winograd F(2,3) kernels: 1.5x fewer MFMAs.
+// The packed weight image differs (G-transformed along kx), so pack and launch must agree on this predicate.
+// The threshold is a run-time option ("winograd_min_cout", cwfa_set_option): 33 = default, a huge value = direct only.
+extern int g_cwfa_wino_min_cout;
+static inline bool cwfa_wino_selected(int ks, int Cout) { return ks == 3 && Cout >= g_cwfa_wino_min_cout; }
+
+int64_t cwfa_wino_packed_floats(int Cout, int Cin);
+int cwfa_wino_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream);
+int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t x_bs,
+                   int64_t y_bs, const cwfa_conv_opts& o, hipStream_t stream);
+// fused sub-network layer, 64 channels: y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x)
+int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1, float* y,
+                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream);

@@ -1,0 +1,426 @@
+// 3x3 convolution as a 1-D Winograd F(2,3) implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Along W, two adjacent outputs of a 3-tap filter need 4 multiplies instead of 6 (Winograd minimal filtering):
+//     input  window d0..d3 (cols 2t-1 .. 2t+2):  V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3
+//     filter row g0,g1,g2:                       U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
+//     M_i = sum_{ky,ci} U_i[ky][ci][co] * V_i[ci][row+ky][t]
+//     out(2t) = M0 + M1 + M2,   out(2t+1) = M1 - M2 - M3
+// so per (ky, ci-pair) a wave issues 4 MFMAs (one per Winograd component, lane = tile t = an output PIXEL PAIR) for 64
+// output pixels where the direct kernel (conv2d.hip) needs 6: 1.5x fewer matrix instructions for the same result (exact
+// in real arithmetic; in fp32 the extra rounding is ~1e-7 relative, tests keep the 1e-4 parity bound).
+//
+// GEMM roles as in conv2d.hip: M = output channels (A = transformed weights), N = 32 tiles of one image row, K = ci pairs.
+// Block = WM x WN waves, wave = MT x 32 channels x (1 row x 64 pixels), 4 accumulator sets.  Per K-chunk the block stages
+// V[4][CK][rows+2][32] (input transform applied on the way into LDS, zero padding / load-side affine / skip add included)
+// and U[3][4][CK][CT].  The output transform runs on the accumulators in registers; a lane then owns two adjacent pixels
+// and stores them as one 8-byte word (256 B contiguous per half-wave).
+#include "conv_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+template <int CK_, int MT_, int WM_, int WN_>
+struct WCfg {
+    static constexpr int CK = CK_, MT = MT_, WM = WM_, WN = WN_;
+    static constexpr int NTHREADS = 64 * WM * WN;
+    static constexpr int CT = 32 * MT * WM;          // output channels per block
+    static constexpr int TR = WN;                    // output rows per block (one per pixel-wave)
+    static constexpr int TCOLS = 64;                 // output columns per block = 32 tiles
+    static constexpr int XR = TR + 2;
+    static constexpr int VPLANE = CK * XR * 32;      // floats per Winograd component
+    static constexpr int VS = 4 * VPLANE;
+    static constexpr int US = 12 * CK * CT;
+    static constexpr int VPT = VPLANE / NTHREADS;    // (channel,row,tile) positions per thread
+    static constexpr int UPT = (US / 4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int LDS_BYTES = (VS + US) * 4;
+    static_assert(VPLANE % NTHREADS == 0 && NTHREADS % 32 == 0, "staging map assumes whole tile rows per thread stride");
+};
+
+struct WParams {
+    const float* x;
+    const float* wp;
+    float* y;
+    int B, Cin, H, W, Cout, nchunks, tiles_x, tiles_y;
+    int64_t x_bs, y_bs;
+    cwfa_conv_opts o;
+    const float* w1x1;
+    const float* b1x1;
+};
+
+struct WTile {
+    int wm, wn, kh, l31, ct, b, row0, col0;
+};
+
+template <class C>
+__device__ __forceinline__ WTile make_wtile(const WParams& p) {
+    WTile t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    t.wm = wave / C::WN;
+    t.wn = wave % C::WN;
+    t.kh = lane >> 5;
+    t.l31 = lane & 31;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    t.ct = blockIdx.y;
+    t.b = blockIdx.z;
+    t.row0 = ty * C::TR;
+    t.col0 = tx * C::TCOLS;
+    return t;
+}
+
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// ------------------------------------------------------------------------------------------------ main loop
+template <class C, bool PRO>
+__device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, float* Vs, float* Us,
+                                              f32x16 (&acc)[C::MT][4]) {
+    const int tid = threadIdx.x;
+    const int64_t HW = (int64_t)p.H * p.W;
+    constexpr int RSTEP = C::NTHREADS / 32;
+
+    // staging map: this thread always handles tile column tt = tid % 32; element i covers (channel ci[i], tile row ri[i])
+    const int tt = tid & 31;
+    int coff[4];
+    unsigned cmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gc = t.col0 + 2 * tt - 1 + j;
+        const bool ok = gc >= 0 && gc < p.W;
+        cmask |= ok ? (1u << j) : 0u;
+        coff[j] = ok ? gc : 0;
+    }
+    int roff[C::VPT], cloc[C::VPT], vdst[C::VPT];
+    unsigned rmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::VPT; ++i) {
+        const int rc = (tid >> 5) + i * RSTEP;
+        const int r = rc % C::XR, c = rc / C::XR;
+        const int gr = t.row0 + r - 1;
+        const bool ok = gr >= 0 && gr < p.H;
+        rmask |= ok ? (1u << i) : 0u;
+        cloc[i] = c;
+        roff[i] = (ok ? gr : 0) * p.W;
+        vdst[i] = (c * C::XR + r) * 32 + tt;
+    }
+    const float* xb = p.x + (int64_t)t.b * p.x_bs;
+    const float* ab = (PRO && p.o.in_add) ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : nullptr;
+    const float* wb = p.wp + (int64_t)t.ct * p.nchunks * C::US;
+    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && ab != nullptr;
+    const float* scb = has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : nullptr;
+    const float* shb = has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : nullptr;
+
+    constexpr int NP = PRO ? C::VPT : 1;
+    f32x4 dr[C::VPT], ar[NP];
+    float sr[NP], hr[NP];
+    f32x4 ur[C::UPT];
+
+    // all loads unconditional (clamped addresses), nothing waits here; masking / affine / transform happen at commit
+    auto prefetch = [&](int chunk) {
+        const int c0 = chunk * C::CK;
+#pragma unroll
+        for (int i = 0; i < C::VPT; ++i) {
+            int ci = c0 + cloc[i];
+            ci = ci < p.Cin ? ci : p.Cin - 1;
+            const float* src = xb + (int64_t)ci * HW + roff[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dr[i][j] = src[coff[j]];
+            if constexpr (PRO) {
+                if (has_aff) {
+                    sr[i] = scb[ci];
+                    hr[i] = shb[ci];
+                }
+                if (has_add) {
+                    const float* asrc = ab + (int64_t)ci * HW + roff[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ar[i][j] = asrc[coff[j]];
+                }
+            }
+        }
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wb + (int64_t)chunk * C::US);
+#pragma unroll
+        for (int i = 0; i < C::UPT; ++i) {
+            const int e = tid + i * C::NTHREADS;
+            ur[i] = w4[e < C::US / 4 ? e : 0];
+        }
+    };
+    auto commit = [&](int chunk) {
+        const int c0 = chunk * C::CK;
+#pragma unroll
+        for (int i = 0; i < C::VPT; ++i) {
+            const bool rc_ok = ((rmask >> i) & 1u) && (c0 + cloc[i] < p.Cin);
+            float d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = dr[i][j];
+                if constexpr (PRO) {
+                    if (has_aff) v = v * sr[i] + hr[i];
+                    if (has_add) v += ar[i][j];
+                }
+                d[j] = (rc_ok && ((cmask >> j) & 1u)) ? v : 0.f;         // zero padding AFTER the load-side affine
+            }
+            float* dst = Vs + vdst[i];
+            dst[0 * C::VPLANE] = d[0] - d[2];
+            dst[1 * C::VPLANE] = d[1] + d[2];
+            dst[2 * C::VPLANE] = d[2] - d[1];
+            dst[3 * C::VPLANE] = d[1] - d[3];
+        }
+#pragma unroll
+        for (int i = 0; i < C::UPT; ++i) {
+            const int e = tid + i * C::NTHREADS;
+            if (e < C::US / 4) reinterpret_cast<f32x4*>(Us)[e] = ur[i];
+        }
+    };
+
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][xi][r] = 0.f;
+
+    const float* ulane = Us + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
+    const float* vlane = Vs + (t.kh * C::XR + t.wn) * 32 + t.l31;
+
+    prefetch(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        if (chunk) __syncthreads();
+        commit(chunk);
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int kk = 0; kk < C::CK / 2; ++kk) {
+                    const float bv = vlane[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m) {
+                        const float a = ulane[((ky * 4 + xi) * C::CK + 2 * kk) * C::CT + m * 32];
+                        acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[m][xi], 0, 0, 0);
+                    }
+                }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ epilogues
+enum { WEPI_GENERIC = 0, WEPI_NONE, WEPI_ELU, WEPI_PRELU, WEPI_RES_PRELU };
+
+template <int EPI>
+struct WEpi {
+    static constexpr int ACT1 = EPI == WEPI_ELU ? CWFA_ACT_ELU : EPI == WEPI_PRELU ? CWFA_ACT_PRELU : CWFA_ACT_NONE;
+    static constexpr bool RES = EPI == WEPI_RES_PRELU;
+    static constexpr int ACT2 = EPI == WEPI_RES_PRELU ? CWFA_ACT_PRELU : CWFA_ACT_NONE;
+};
+
+template <int ACT>
+__device__ __forceinline__ float wact(float v, float alpha) {
+    if constexpr (ACT == CWFA_ACT_ELU) return cwfa_elu(v);
+    if constexpr (ACT == CWFA_ACT_PRELU) return v > 0.f ? v : alpha * v;
+    return v;
+}
+
+template <class C, int EPI>
+__device__ __forceinline__ void wino_epilogue(const WParams& p, const WTile& t, f32x16 (&acc)[C::MT][4], float* smem) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int row = t.row0 + t.wn, col = t.col0 + 2 * t.l31;
+    const bool ok0 = row < p.H && col < p.W, ok1 = row < p.H && col + 1 < p.W;
+    float* yb = p.y + (int64_t)t.b * p.y_bs + (int64_t)row * p.W + col;
+    const bool vec = ok1 && ((HW | p.W | p.y_bs) & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.y) & 7) == 0);
+    if constexpr (EPI == WEPI_GENERIC) {
+        // runtime-switched activations: the two output pixels go through LDS so ONE copy of the code serves all rows
+        const float alpha = (p.o.prelu_alpha && (p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU)) ? *p.o.prelu_alpha : 0.f;
+        const float* rb = p.o.residual ? p.o.residual + (int64_t)t.b * p.o.res_bs + (int64_t)row * p.W + col : nullptr;
+        __syncthreads();
+        float* mine = smem + (threadIdx.x >> 6) * 2048 + (threadIdx.x & 63);      // [2][16] floats x 64 lanes per wave
+        for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+            for (int mm = 0; mm < C::MT; ++mm)
+                if (mm == m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        mine[r * 64] = (acc[mm][0][r] + acc[mm][1][r]) + acc[mm][2][r];
+                        mine[(16 + r) * 64] = (acc[mm][1][r] - acc[mm][2][r]) - acc[mm][3][r];
+                    }
+                }
+            for (int r = 0; r < 16; ++r) {
+                const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                if (co >= p.Cout) continue;
+                const float bias = p.o.bias ? p.o.bias[co] : 0.f;
+                for (int px = 0; px < 2; ++px) {
+                    if (!(px ? ok1 : ok0)) continue;
+                    float v = cwfa_act(mine[(px * 16 + r) * 64] + bias, p.o.act, alpha);
+                    if (rb) v += rb[(int64_t)co * HW + px];
+                    yb[(int64_t)co * HW + px] = cwfa_act(v, p.o.act2, alpha);
+                }
+            }
+        }
+    } else {
+        typedef WEpi<EPI> E;
+        float alpha = 0.f;
+        if constexpr (E::ACT1 == CWFA_ACT_PRELU || E::ACT2 == CWFA_ACT_PRELU) alpha = *p.o.prelu_alpha;
+        const float* rb = nullptr;
+        if constexpr (E::RES) rb = p.o.residual + (int64_t)t.b * p.o.res_bs + (int64_t)row * p.W + col;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                if (co >= p.Cout) continue;
+                const float bias = p.o.bias ? p.o.bias[co] : 0.f;
+                float e0 = (acc[m][0][r] + acc[m][1][r]) + acc[m][2][r];
+                float e1 = (acc[m][1][r] - acc[m][2][r]) - acc[m][3][r];
+                e0 = wact<E::ACT1>(e0 + bias, alpha);
+                e1 = wact<E::ACT1>(e1 + bias, alpha);
+                const int64_t o = (int64_t)co * HW;
+                if (vec) {
+                    if constexpr (E::RES) {
+                        const f32x2 rr = *reinterpret_cast<const f32x2*>(rb + o);
+                        e0 += rr[0];
+                        e1 += rr[1];
+                    }
+                    f32x2 out = {wact<E::ACT2>(e0, alpha), wact<E::ACT2>(e1, alpha)};
+                    *reinterpret_cast<f32x2*>(yb + o) = out;
+                } else {
+                    if (ok0) {
+                        if constexpr (E::RES) e0 += rb[o];
+                        yb[o] = wact<E::ACT2>(e0, alpha);
+                    }
+                    if (ok1) {
+                        if constexpr (E::RES) e1 += rb[o + 1];
+                        yb[o + 1] = wact<E::ACT2>(e1, alpha);
+                    }
+                }
+            }
+    }
+}
+
+template <class C, int EPI, bool PRO>
+__global__ __launch_bounds__(C::NTHREADS, 1) void conv3x3_wino_kernel(WParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WTile t = make_wtile<C>(p);
+    f32x16 acc[C::MT][4];
+    wino_mainloop<C, PRO>(p, t, smem, smem + C::VS, acc);
+    wino_epilogue<C, EPI>(p, t, acc, smem);
+}
+
+// ---- weight transform + repack: torch [Cout][Cin][3][3] -> [cout tile][chunk][ky][xi][ck][CT]
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                                        int CT, int CK, int nchunks, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % CT);
+    const int ck = (int)((i / CT) % CK);
+    const int xi = (int)((i / ((int64_t)CT * CK)) % 4);
+    const int ky = (int)((i / ((int64_t)CT * CK * 4)) % 3);
+    const int chunk = (int)((i / ((int64_t)CT * CK * 12)) % nchunks);
+    const int ctile = (int)(i / ((int64_t)CT * CK * 12 * nchunks));
+    const int co = ctile * CT + col, ci = chunk * CK + ck;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+        const float* g = w + (((int64_t)co * Cin + ci) * 3 + ky) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        v = xi == 0 ? g0 : xi == 1 ? ((g0 + g1) + g2) * 0.5f : xi == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+    }
+    out[i] = v;
+}
+
+typedef WCfg<8, 2, 1, 8> W64;       // Cout <= 64: 64 ch x 8 rows x 64 cols, 512 threads
+typedef WCfg<8, 2, 2, 4> W128;      // Cout  > 64: 128 ch x 4 rows x 64 cols, 512 threads
+
+struct WSel {
+    int CT, CK;
+};
+WSel wsel(int Cout) { return Cout <= 64 ? WSel{W64::CT, W64::CK} : WSel{W128::CT, W128::CK}; }
+
+template <class C, int EPI, bool PRO>
+int wlaunch(WParams p, hipStream_t stream) {
+    p.tiles_x = (p.W + C::TCOLS - 1) / C::TCOLS;
+    p.tiles_y = (p.H + C::TR - 1) / C::TR;
+    p.nchunks = (p.Cin + C::CK - 1) / C::CK;
+    const int ctiles = (p.Cout + C::CT - 1) / C::CT;
+    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
+                 "cwfa_conv2d_f32: grid too large");
+    constexpr int LDS = EPI == WEPI_GENERIC && C::LDS_BYTES < C::NTHREADS * 128 ? C::NTHREADS * 128 : C::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<C, EPI, PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            cwfa_set_error("cwfa_conv2d_f32 (winograd): hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
+            return CWFA_E_HIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<C, EPI, PRO>), grid, dim3(C::NTHREADS), LDS, stream, p);
+    CWFA_LAUNCH_CHECK("cwfa_conv2d_f32 (winograd)");
+    return CWFA_OK;
+}
+
+int classify(const cwfa_conv_opts& o) {
+    const bool res = o.residual != nullptr;
+    if (!res && o.act2 == CWFA_ACT_NONE) {
+        if (o.act == CWFA_ACT_NONE) return WEPI_NONE;
+        if (o.act == CWFA_ACT_ELU) return WEPI_ELU;
+        if (o.act == CWFA_ACT_PRELU) return WEPI_PRELU;
+    }
+    if (res && o.act == CWFA_ACT_NONE && o.act2 == CWFA_ACT_PRELU) return WEPI_RES_PRELU;
+    return WEPI_GENERIC;
+}
+
+}  // namespace
+
+int64_t cwfa_wino_packed_floats(int Cout, int Cin) {
+    const WSel s = wsel(Cout);
+    const int64_t ctiles = (Cout + s.CT - 1) / s.CT, nchunks = (Cin + s.CK - 1) / s.CK;
+    return ctiles * nchunks * 12 * s.CK * s.CT;
+}
+
+int cwfa_wino_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream) {
+    const WSel s = wsel(Cout);
+    const int64_t total = cwfa_wino_packed_floats(Cout, Cin);
+    const int nchunks = (Cin + s.CK - 1) / s.CK;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, packed, Cout, Cin, s.CT,
+                       s.CK, nchunks, total);
+    CWFA_LAUNCH_CHECK("cwfa_conv2d_pack_f32 (winograd)");
+    return CWFA_OK;
+}
+
+int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t x_bs,
+                   int64_t y_bs, const cwfa_conv_opts& o, hipStream_t stream) {
+    WParams p{};
+    p.x = x; p.wp = w_packed; p.y = y;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.x_bs = x_bs; p.y_bs = y_bs;
+    p.o = o;
+    const bool pro = o.in_scale || o.in_add;
+    const int epi = classify(o);
+    if (Cout <= 64) {
+        if (pro) return wlaunch<W64, WEPI_GENERIC, true>(p, stream);
+        switch (epi) {
+            case WEPI_NONE: return wlaunch<W64, WEPI_NONE, false>(p, stream);
+            case WEPI_ELU: return wlaunch<W64, WEPI_ELU, false>(p, stream);
+            case WEPI_PRELU: return wlaunch<W64, WEPI_PRELU, false>(p, stream);
+            case WEPI_RES_PRELU: return wlaunch<W64, WEPI_RES_PRELU, false>(p, stream);
+            default: return wlaunch<W64, WEPI_GENERIC, false>(p, stream);
+        }
+    }
+    if (pro) {
+        if (epi == WEPI_PRELU) return wlaunch<W128, WEPI_PRELU, true>(p, stream);
+        return wlaunch<W128, WEPI_GENERIC, true>(p, stream);
+    }
+    switch (epi) {
+        case WEPI_NONE: return wlaunch<W128, WEPI_NONE, false>(p, stream);
+        case WEPI_PRELU: return wlaunch<W128, WEPI_PRELU, false>(p, stream);
+        default: return wlaunch<W128, WEPI_GENERIC, false>(p, stream);
+    }
+}
+
+int cwfa_wino_layer(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int64_t,
+                    int64_t, hipStream_t) {
+    cwfa_set_error("cwfa_subnet_layer_f32: Winograd fused layer not built");
+    return CWFA_E_SHAPE;
+}

@@ -443,6 +443,12 @@ def axpby(x, a, z=None, b=0.0):
     return out
 
 
+def set_option(name, value):
+    """Process-wide tuning option of the library (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed
+    before a change of "winograd_min_cout" must be re-packed."""
+    check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")
+
+
 def concat_channels(parts):
     """torch.cat(parts, 1) through the strided plane-copy kernel (coupling_layers.py:74-87 materialise this too)."""
     L = _lib.lib()

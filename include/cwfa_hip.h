@@ -48,6 +48,11 @@ enum { CWFA_ACT_NONE = 0, CWFA_ACT_ELU = 1, CWFA_ACT_PRELU = 2, CWFA_ACT_GELU = 
 
 int cwfa_version(void);
 const char* cwfa_last_error(void);
+/* process-wide tuning options (set before packing weights; pack and launch consult the same value):
+ *   "winograd_min_cout" : 3x3 convolutions with at least this many output channels use the Winograd F(2,3) kernels
+ *                         (default 33; a value above every Cout selects the direct kernels everywhere).
+ * returns 0, or CWFA_E_INVAL for an unknown name. */
+int cwfa_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Haar wavelets

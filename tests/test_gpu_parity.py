@@ -155,6 +155,46 @@ def test_subnet_layer_fused_vs_torch_cpu(shape):
     assert_close(y2, ref, 3e-6)
 
 
+@pytest.mark.parametrize("cfg", [
+    # (B, Cin, H, W, Cout): 3x3 convs through the Winograd F(2,3) kernels (threshold lowered to 33 for the test)
+    (1, 64, 16, 64, 64), (2, 29, 21, 37, 48), (1, 8, 9, 130, 40), (1, 70, 7, 63, 130), (1, 256, 8, 64, 128), (1, 6, 12, 66, 256),
+])
+def test_conv3x3_winograd_vs_torch_cpu(cfg):
+    from cwfa_amd import ops
+    B, Cin, H, W, Cout = cfg
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(Cin * Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    alpha = torch.tensor([0.2])
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
+    ref_pro = F.prelu(F.conv2d(xin, w.double(), b.double(), padding=1), alpha.double())
+    ops.set_option("winograd_min_cout", 33)
+    try:
+        pc = ops.pack_conv_weight(w.cuda())
+        got = {
+            "plain": ops.conv2d(x.cuda(), pc, bias=b.cuda()),
+            "elu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="elu"),
+            "prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda()),
+            "res_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), residual=res.cuda(), act2="prelu", prelu_alpha=alpha.cuda()),
+            "generic": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="gelu", residual=res.cuda(), act2="relu"),
+            "pro_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
+                                    in_shift=sh.cuda(), in_add=add.cuda()),
+        }
+    finally:
+        ops.set_option("winograd_min_cout", 65)
+    want = {"plain": ref, "elu": F.elu(ref), "prelu": F.prelu(ref, alpha.double()),
+            "res_prelu": F.prelu(ref + res.double(), alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
+            "pro_prelu": ref_pro}
+    for k in want:
+        assert_close(got[k], want[k], 5e-6, f"winograd {k}")
+
+
 def test_conv2d_generic_epilogue_combo():
     """A combination without a specialised epilogue (GELU -> +residual -> ReLU) takes the runtime path."""
     from cwfa_amd import ops
