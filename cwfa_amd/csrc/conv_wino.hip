@@ -330,6 +330,120 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 typedef WCfg<8, 2, 1, 8> W64;       // Cout <= 64: 64 ch x 8 rows x 64 cols, 512 threads
 typedef WCfg<8, 2, 2, 4> W128;      // Cout  > 64: 128 ch x 4 rows x 64 cols, 512 threads
 
+// ------------------------------------------------------------------------------------------------ fused sub-network layer
+// y = ELU( W1x1 . ELU( conv3x3(x) + b3 ) + b1 + x ), 64 channels, ONE launch (networks.py:624-631,660-665).
+// After the Winograd main loop a lane holds, per hidden channel, the four components of ONE pixel pair.  The output
+// transform + bias + ELU produce the hidden value of the even pixel (pass 0) and of the odd pixel (pass 1) in place, and
+// those registers ARE the B operand of the 1x1 GEMM (k-pair of register r = channels {32m + row(r), +4} in the two lane
+// halves, N = 32 even resp. odd pixels).  Four chained-MFMA passes q = (cout half, pixel parity); the VALU work (output
+// transform, ELU, residual add, store) is slotted between the MFMAs; both parities of a channel leave as one 8-byte store.
+__device__ __forceinline__ f32x2 ld2(const float* base, unsigned byte_off, bool vec, bool ok1) {
+    asm volatile("" : "+v"(byte_off));
+    const char* q = reinterpret_cast<const char*>(base) + byte_off;
+    if (vec) return *reinterpret_cast<const f32x2*>(q);
+    f32x2 v;
+    v[0] = *reinterpret_cast<const float*>(q);
+    v[1] = ok1 ? *reinterpret_cast<const float*>(q + 4) : 0.f;
+    return v;
+}
+__device__ __forceinline__ void st2(float* base, unsigned byte_off, f32x2 v, bool vec, bool ok0, bool ok1) {
+    asm volatile("" : "+v"(byte_off));
+    char* q = reinterpret_cast<char*>(base) + byte_off;
+    if (vec) {
+        *reinterpret_cast<f32x2*>(q) = v;
+    } else {
+        if (ok0) *reinterpret_cast<float*>(q) = v[0];
+        if (ok1) *reinterpret_cast<float*>(q + 4) = v[1];
+    }
+}
+__device__ __forceinline__ float ld1(const float* base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+__global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p) {
+    typedef W64 C;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Us = smem + C::VS;
+    const WTile t = make_wtile<C>(p);
+    f32x16 acc[2][4];
+    wino_mainloop<C, false>(p, t, smem, Us, acc);
+
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int row = t.row0 + t.wn, col = t.col0 + 2 * t.l31;
+    const bool ok0 = row < p.H && col < p.W, ok1 = row < p.H && col + 1 < p.W;
+    const bool vec = ok1 && ((HW | p.W | p.x_bs | p.y_bs) & 1) == 0 &&
+                     (((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.y)) & 7) == 0);
+    const float* xb = p.x + (int64_t)t.b * p.x_bs;
+    float* yb = p.y + (int64_t)t.b * p.y_bs;
+    const unsigned HW4 = (unsigned)HW * 4u;
+    // per-lane byte offset of this lane's pixel pair in channel 4*kh; channel K adds the scalar K*HW4
+    const unsigned oo = (ok0 ? (unsigned)(row * p.W + col) * 4u : 0u) + (unsigned)t.kh * 4u * HW4;
+
+    f32x16 b3v[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b3v[m][r] = ld1(p.o.bias, (unsigned)(m * 32 + acc_row(r, 0)) * 4u + (unsigned)t.kh * 16u);
+
+    // stage the 1x1 panel (4096 floats) where the transformed 3x3 weights were
+    __syncthreads();
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.w1x1);
+        f32x4* dst = reinterpret_cast<f32x4*>(Us);
+        for (int e = threadIdx.x; e < 1024; e += C::NTHREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    const float* wl = Us + (threadIdx.x & 63);
+
+    auto load_res = [&](int mo, f32x2 (&res)[16]) {           // residual x + 1x1 bias of 16 output channels, both pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned K = (unsigned)(mo * 32 + acc_row(r, 0));
+            const float b1 = ld1(p.b1x1, K * 4u + (unsigned)t.kh * 16u);
+            res[r] = ld2(xb, K * HW4 + oo, vec, ok1) + b1;
+        }
+    };
+    f32x16 yq[4];
+    f32x2 rq0[16], rq1[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mo = q >> 1, par = q & 1;
+        if (q == 2) load_res(0, rq0);
+        if (q == 3) load_res(1, rq1);
+        float a_next = wl[(0 * 2 + mo) * 64];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = m * 16 + r;
+                const float a = a_next;
+                if (j + 1 < 32) a_next = wl[((j + 1) * 2 + mo) * 64];
+                if (q == 0) acc[m][0][r] = cwfa_elu(((acc[m][0][r] + acc[m][1][r]) + acc[m][2][r]) + b3v[m][r]);
+                if (q == 1) acc[m][1][r] = cwfa_elu(((acc[m][1][r] - acc[m][2][r]) - acc[m][3][r]) + b3v[m][r]);
+                if (j == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][par][r], zero, 0, 0, 0);
+                } else {
+                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][par][r], yq[q], 0, 0, 0);
+                }
+                if (q == 3 && (j & 1)) {                    // output channels 0..31 are complete: one per two k-steps
+                    const int rr = j >> 1;
+                    const unsigned K = (unsigned)acc_row(rr, 0);
+                    f32x2 o = {cwfa_elu(yq[0][rr] + rq0[rr][0]), cwfa_elu(yq[1][rr] + rq0[rr][1])};
+                    if (ok0) st2(yb, K * HW4 + oo, o, vec, ok0, ok1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {                       // tail: output channels 32..63
+        const unsigned K = (unsigned)(32 + acc_row(rr, 0));
+        f32x2 o = {cwfa_elu(yq[2][rr] + rq1[rr][0]), cwfa_elu(yq[3][rr] + rq1[rr][1])};
+        if (ok0) st2(yb, K * HW4 + oo, o, vec, ok0, ok1);
+    }
+}
+
 struct WSel {
     int CT, CK;
 };
@@ -419,8 +533,32 @@ int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int C
     }
 }
 
-int cwfa_wino_layer(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int64_t,
-                    int64_t, hipStream_t) {
-    cwfa_set_error("cwfa_subnet_layer_f32: Winograd fused layer not built");
-    return CWFA_E_SHAPE;
+int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1, float* y,
+                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream) {
+    typedef W64 C;
+    WParams p{};
+    p.x = x; p.wp = w3_packed; p.y = y;
+    p.B = B; p.Cin = 64; p.H = H; p.W = W; p.Cout = 64;
+    p.x_bs = x_bs; p.y_bs = y_bs;
+    p.o.bias = b3;
+    p.w1x1 = w1_panel;
+    p.b1x1 = b1;
+    p.tiles_x = (W + C::TCOLS - 1) / C::TCOLS;
+    p.tiles_y = (H + C::TR - 1) / C::TR;
+    p.nchunks = 64 / C::CK;
+    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_subnet_layer_f32: grid too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_layer_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            cwfa_set_error("cwfa_subnet_layer_f32: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return CWFA_E_HIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), 1, B);
+    hipLaunchKernelGGL(wino_layer_kernel, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    CWFA_LAUNCH_CHECK("cwfa_subnet_layer_f32 (winograd)");
+    return CWFA_OK;
 }

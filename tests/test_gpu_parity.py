@@ -147,8 +147,14 @@ def test_subnet_layer_fused_vs_torch_cpu(shape):
     F = torch.nn.functional
     xd = x.double()
     ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
-    y = ops.subnet_layer(x.cuda(), ops.pack_conv_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()), b1.cuda())
-    assert_close(y, ref, 3e-6)
+    for min_cout in (33, 1 << 20):           # Winograd fused kernel (default) and the direct fused kernel
+        ops.set_option("winograd_min_cout", min_cout)
+        try:
+            y = ops.subnet_layer(x.cuda(), ops.pack_conv_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()),
+                                 b1.cuda())
+        finally:
+            ops.set_option("winograd_min_cout", 33)
+        assert_close(y, ref, 3e-6, f"fused layer, winograd_min_cout={min_cout}")
     # the unfused two-launch form agrees too
     h = ops.conv2d(x.cuda(), ops.pack_conv_weight(w3.cuda()), bias=b3.cuda(), act="elu")
     y2 = ops.conv2d(h, ops.pack_conv_weight(w1.cuda()), bias=b1.cuda(), residual=x.cuda(), act2="elu")
@@ -187,7 +193,7 @@ def test_conv3x3_winograd_vs_torch_cpu(cfg):
                                     in_shift=sh.cuda(), in_add=add.cuda()),
         }
     finally:
-        ops.set_option("winograd_min_cout", 65)
+        ops.set_option("winograd_min_cout", 33)
     want = {"plain": ref, "elu": F.elu(ref), "prelu": F.prelu(ref, alpha.double()),
             "res_prelu": F.prelu(ref + res.double(), alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
             "pro_prelu": ref_pro}
