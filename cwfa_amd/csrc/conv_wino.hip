@@ -35,7 +35,8 @@ struct WCfg {
     static constexpr int US = 12 * CK * CT;
     static constexpr int VPT = VPLANE / NTHREADS;    // (channel,row,tile) positions per thread
     static constexpr int UPT = (US / 4 + NTHREADS - 1) / NTHREADS;
-    static constexpr int LDS_BYTES = (VS + US) * 4;
+    static constexpr int BUF = VS + US;              // floats per LDS buffer (two buffers, see wino_mainloop)
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
     static_assert(VPLANE % NTHREADS == 0 && NTHREADS % 32 == 0, "staging map assumes whole tile rows per thread stride");
 };
 
@@ -145,8 +146,10 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
             ur[i] = w4[e < C::US / 4 ? e : 0];
         }
     };
-    auto commit = [&](int chunk) {
+    auto commit = [&](int chunk, int buf) {
         const int c0 = chunk * C::CK;
+        float* Vb = Vs + buf * C::BUF;
+        float* Ub = Us + buf * C::BUF;
 #pragma unroll
         for (int i = 0; i < C::VPT; ++i) {
             const bool rc_ok = ((rmask >> i) & 1u) && (c0 + cloc[i] < p.Cin);
@@ -160,7 +163,7 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
                 }
                 d[j] = (rc_ok && ((cmask >> j) & 1u)) ? v : 0.f;         // zero padding AFTER the load-side affine
             }
-            float* dst = Vs + vdst[i];
+            float* dst = Vb + vdst[i];
             dst[0 * C::VPLANE] = d[0] - d[2];
             dst[1 * C::VPLANE] = d[1] + d[2];
             dst[2 * C::VPLANE] = d[2] - d[1];
@@ -169,7 +172,7 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #pragma unroll
         for (int i = 0; i < C::UPT; ++i) {
             const int e = tid + i * C::NTHREADS;
-            if (e < C::US / 4) reinterpret_cast<f32x4*>(Us)[e] = ur[i];
+            if (e < C::US / 4) reinterpret_cast<f32x4*>(Ub)[e] = ur[i];
         }
     };
 
@@ -180,15 +183,18 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][xi][r] = 0.f;
 
-    const float* ulane = Us + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
-    const float* vlane = Vs + (t.kh * C::XR + t.wn) * 32 + t.l31;
+    const float* ulane0 = Us + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
+    const float* vlane0 = Vs + (t.kh * C::XR + t.wn) * 32 + t.l31;
 
-    prefetch(0);
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        if (chunk) __syncthreads();
-        commit(chunk);
-        __syncthreads();
-        if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
+    // Two LDS buffers, ONE barrier per chunk, and a STAGGER between the two waves that share a SIMD (waves w and w+4 of
+    // a 512-thread block): the late half does [MFMAs of chunk c, then stage chunk c+1], the early half [stage chunk c+1
+    // (its global loads were issued a whole chunk earlier), then MFMAs of chunk c].  Run in lockstep, both waves of a SIMD
+    // would stage at the same time and leave the matrix pipe idle ~28 % of the chunk; staggered, one of them always has
+    // MFMAs to issue (MI355X_MICROARCH "Two waves per SIMD", item 9).
+    const bool early = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= C::NTHREADS / 2;
+    auto mfmas = [&](int cur) {
+        const float* ulane = ulane0 + cur * C::BUF;
+        const float* vlane = vlane0 + cur * C::BUF;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -202,6 +208,20 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
                         acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[m][xi], 0, 0, 0);
                     }
                 }
+    };
+    prefetch(0);
+    commit(0, 0);
+    if (early && 1 < p.nchunks) prefetch(1);
+    __syncthreads();
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < p.nchunks;
+        if (early && more) commit(chunk + 1, cur ^ 1);
+        const int pf = early ? chunk + 2 : chunk + 1;
+        if (pf < p.nchunks) prefetch(pf);
+        mfmas(cur);                                      // ONE copy of the MFMA block (two copies spilled)
+        if (!early && more) commit(chunk + 1, cur ^ 1);
+        __syncthreads();
     }
 }
 
