@@ -126,7 +126,7 @@ def inverse_pass(conv_inn, cond_nets, cond_input, mean_vols_cache, low=None, tem
         else:
             z = sample_z_truncated((up.shape[0],) + tuple(g.global_out_shapes[0]), device=up.device,
                                    temperature=temperature)
-        up, _ = g([z, up], c=cond_processed, rev=True)
+        up, _ = g([z, up], c=cond_processed, rev=True, jac=getattr(g, "_plan", None) is None)   # log-det is discarded
         if n_samples > 1:                         # CWFA.py:913-914: average the samples
             parts = up.view(n_samples, -1, *up.shape[1:])
             acc = ops.axpby(parts[0], 1.0 / n_samples)

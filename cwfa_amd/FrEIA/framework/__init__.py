@@ -205,7 +205,7 @@ class GraphINN(InvertibleModule):
         if len(c) != len(self.condition_nodes):
             raise ValueError(f"Got {len(c)} conditions, but expected {len(self.condition_nodes)}.")
         if self._plan is not None and not intermediate_outputs:
-            return self._plan.run(x_or_z, c, rev, sumsq)
+            return self._plan.run(x_or_z, c, rev, sumsq, jac)
         if any(t is None for t in x_or_z):
             raise ValueError("None (an all-zero latent) is only understood by fused step plans")
         return self._walk(x_or_z, c, rev, jac, intermediate_outputs)
@@ -332,19 +332,21 @@ class _CatStepPlan:
                 pending = None
         return stages, pending
 
-    def run(self, x_or_z, c, rev, sumsq=None):
+    def run(self, x_or_z, c, rev, sumsq=None, jac=True):
+        """``jac=False`` skips the log-det reduction (the reconstruction loop discards it, CWFA.py:912) and returns
+        ``None`` in its place."""
         g = self.graph
         cond_of = dict(zip(g.condition_nodes, c))
         stages, pending = self._stages(cond_of, rev)
         first = next(t for t in x_or_z if t is not None)
-        acc = torch.zeros(first.shape[0], dtype=torch.float64, device=first.device)
+        acc = torch.zeros(first.shape[0], dtype=torch.float64, device=first.device) if jac else None
         if rev:
             z, low = x_or_z[self.flow_out_idx], x_or_z[self.low_out_idx]
             if pending is not None:
                 stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
             out = ops.chain_inv(z, low, stages, logdet=acc)
             res = out if not g.force_tuple_output else (out,)
-            return res, acc.to(torch.float32)
+            return res, (acc.to(torch.float32) if jac else None)
         final_perm = None
         if pending is not None:
             if pending[1] == 1:
@@ -354,7 +356,7 @@ class _CatStepPlan:
         z, low = ops.chain_fwd(first, stages, final_perm, logdet=acc, sumsq=sumsq)
         outs = [None, None]
         outs[self.flow_out_idx], outs[self.low_out_idx] = z, low
-        return tuple(outs), acc.to(torch.float32)
+        return tuple(outs), (acc.to(torch.float32) if jac else None)
 
 
 def _lower_cat_step(g: "GraphINN"):

@@ -289,10 +289,10 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const Tile& t, f32
                 for (int r = 0; r < 16; ++r) {
                     const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
                     if (co >= p.Cout || row >= p.H || col >= p.W) continue;
-                    const int cb = p.o.upshuffle2 ? co % Co : co;
+                    const int cb = p.o.upshuffle2 ? co >> 2 : co;
                     int64_t o;
                     if (p.o.upshuffle2) {
-                        const int q = co / Co;
+                        const int q = co & 3;
                         o = (int64_t)cb * (4 * HW) + (int64_t)(2 * row + (q >> 1)) * (2 * p.W) + 2 * col + (q & 1);
                     } else {
                         o = (int64_t)co * HW + (int64_t)row * p.W + col;
@@ -307,31 +307,62 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const Tile& t, f32
         if constexpr (E::ACT1 == CWFA_ACT_PRELU || E::ACT2 == CWFA_ACT_PRELU) alpha = *p.o.prelu_alpha;
         const float* rb = nullptr;
         if constexpr (E::RES) rb = p.o.residual + (int64_t)t.b * p.o.res_bs;
-        const int Co = E::UP ? p.Cout / 4 : p.Cout;
+        if constexpr (E::UP) {
+            // ConvTranspose2d(k2,s2) as a 1x1 conv whose packed output channel is c*4 + (dy*2+dx): registers 4g..4g+3 of
+            // a lane are the 2x2 output patch of ONE channel at this lane's input pixel -> two 8-byte stores per channel,
+            // 256 B contiguous per half-wave and row (the lane-strided 4-byte stores of a naive shuffle were 76 TFLOP/s).
+            const int W2 = 2 * p.W;
+            const bool al = ((W2 | (int)(p.y_bs & 1)) & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.y) & 7) == 0);
 #pragma unroll
-        for (int m = 0; m < C::MT; ++m) {
+            for (int m = 0; m < C::MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
-                if (co >= p.Cout) continue;
-                int cb = co, q = 0;
-                if constexpr (E::UP) {
-                    q = co / Co;
-                    cb = co - q * Co;
+                for (int g = 0; g < 4; ++g) {
+                    const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + 8 * g + 4 * t.kh;      // multiple of 4
+                    if (co >= p.Cout) continue;
+                    const int c = co >> 2;
+                    const float bias = p.o.bias ? p.o.bias[c] : 0.f;
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) {
+                        const int row = t.row0 + t.wn * C::NT + n;
+                        if (row >= p.H || col >= p.W) continue;
+                        float* o = yb + (int64_t)c * (4 * HW) + (int64_t)(2 * row) * W2 + 2 * col;
+                        const float v0 = acc[m][n][4 * g] + bias, v1 = acc[m][n][4 * g + 1] + bias;
+                        const float v2 = acc[m][n][4 * g + 2] + bias, v3 = acc[m][n][4 * g + 3] + bias;
+                        if (al) {
+                            *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                            *reinterpret_cast<float2*>(o + W2) = make_float2(v2, v3);
+                        } else {
+                            o[0] = v0; o[1] = v1; o[W2] = v2; o[W2 + 1] = v3;
+                        }
+                    }
                 }
-                const float bias = p.o.bias ? p.o.bias[cb] : 0.f;
+        } else {
+            // biases of this lane's channels in one batch of unconditional loads (a per-channel "load or 0" branch costs a
+            // vmcnt(0) round trip per channel)
+            float bias[C::MT][16];
 #pragma unroll
-                for (int n = 0; n < C::NT; ++n) {
-                    const int row = t.row0 + t.wn * C::NT + n;
-                    if (row >= p.H || col >= p.W) continue;
-                    int64_t o;
-                    if constexpr (E::UP)
-                        o = (int64_t)cb * (4 * HW) + (int64_t)(2 * row + (q >> 1)) * (2 * p.W) + 2 * col + (q & 1);
-                    else
-                        o = (int64_t)co * HW + (int64_t)row * p.W + col;
-                    float v = act_ct<E::ACT1>(acc[m][n][r] + bias, alpha);
-                    if constexpr (E::RES) v += rb[o];
-                    yb[o] = act_ct<E::ACT2>(v, alpha);
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                    co = co < p.Cout ? co : p.Cout - 1;
+                    bias[m][r] = p.o.bias ? p.o.bias[co] : 0.f;
+                }
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + acc_row(r, t.kh);
+                    if (co >= p.Cout) continue;
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) {
+                        const int row = t.row0 + t.wn * C::NT + n;
+                        if (row >= p.H || col >= p.W) continue;
+                        const int64_t o = (int64_t)co * HW + (int64_t)row * p.W + col;
+                        float v = act_ct<E::ACT1>(acc[m][n][r] + bias[m][r], alpha);
+                        if constexpr (E::RES) v += rb[o];
+                        yb[o] = act_ct<E::ACT2>(v, alpha);
+                    }
                 }
             }
         }
@@ -470,9 +501,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     const int co = ctile * CT + col, ci = chunk * CK + ck;
     float v = 0.f;
     if (co < Cout && ci < Cin) {
-        if (transposed) {   // ConvTranspose2d [Cin][Co][2][2] seen as a 1x1 conv with 4*Co outputs, co = q*Co + c
-            const int Co = Cout / 4, q = co / Co, c = co % Co;
-            v = w[((int64_t)ci * Co + c) * 4 + q];
+        if (transposed) {   // ConvTranspose2d [Cin][Co][2][2] seen as a 1x1 conv with 4*Co outputs, co = c*4 + (dy*2+dx)
+            const int Co = Cout / 4;
+            v = w[((int64_t)ci * Co + (co >> 2)) * 4 + (co & 3)];
         } else {
             v = w[((int64_t)co * Cin + ci) * taps + tap];
         }

@@ -479,6 +479,152 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const float* __restrict_
     }
 }
 
+// ---- row-staged variants (the ones that normally run).  A block owns ONE output row (b, c, h, all w).  Channel and row
+// permutations map whole rows to whole rows, so at every stage the block needs exactly one row of s_k and t_k: it is
+// loaded COALESCED into LDS (as exp(-+s) and t), and only then read at the column the value actually travels through.
+// In the per-element kernels above a column permutation turns every later s/t access into a 64-way gather (measured
+// 1.1 TB/s effective); here all global traffic is full-row streaming.
+struct RowPos {
+    int c, h;
+};
+__device__ __forceinline__ RowPos row_gather(RowPos p, const int64_t* __restrict__ perm, int axis) {
+    if (perm) {
+        if (axis == 1) p.c = (int)perm[p.c];
+        if (axis == 2) p.h = (int)perm[p.h];
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void chain_inv_rows_kernel(const float* __restrict__ z, const float* __restrict__ low,
+                                                             float* __restrict__ x, cwfa_chain ch, int C, int H, int W,
+                                                             int64_t z_bs, int64_t low_bs, int64_t x_bs,
+                                                             double* __restrict__ logdet) {
+    extern __shared__ float rows[];          // [stage][2][W]: e = exp(-s), t      (+ [W] z row)
+    __shared__ double red[16];
+    const int b = blockIdx.z, c = blockIdx.y, h = blockIdx.x;
+    const int64_t HW = (int64_t)H * W;
+    // walk the row coordinates backwards through the stages (uniform over the block)
+    RowPos q[CWFA_CHAIN_MAX], src = RowPos{c, h};          // q[k]: row where stage k reads s,t; src: row of z
+#pragma unroll
+    for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+        if (k < ch.n_stages) {
+            q[k] = src;
+            src = row_gather(src, ch.stage[k].perm, ch.stage[k].perm_axis);
+        }
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+        if (k < ch.n_stages) {
+            const int64_t off = ((int64_t)q[k].c * H + q[k].h) * W;
+            for (int w = threadIdx.x; w < W; w += blockDim.x) {
+                float s, t;
+                stage_st(ch.stage[k], b, off + w, s, t);
+                ssum += s;
+                rows[(2 * k) * W + w] = expf(-s);
+                rows[(2 * k + 1) * W + w] = t;
+            }
+        }
+    float* zrow = rows + 2 * ch.n_stages * W;
+    if (z) {
+        const int64_t off = ((int64_t)src.c * H + src.h) * W;
+        for (int w = threadIdx.x; w < W; w += blockDim.x) zrow[w] = z[b * z_bs + off + w];
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        int wq[CWFA_CHAIN_MAX], w0 = w;                    // wq[k]: column where stage k reads s,t; w0: column of z
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+            if (k < ch.n_stages) {
+                wq[k] = w0;
+                if (ch.stage[k].perm && ch.stage[k].perm_axis == 3) w0 = (int)ch.stage[k].perm[w0];
+            }
+        float v = z ? zrow[w0] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+            if (k < ch.n_stages) v = (v - rows[(2 * k + 1) * W + wq[k]]) * rows[(2 * k) * W + wq[k]];
+        const int64_t o = (int64_t)h * W + w;
+        const float l = low[b * low_bs + (int64_t)c * HW + o];
+        x[b * x_bs + (int64_t)(2 * c) * HW + o] = (l + v) * CWFA_INV_SQRT2_F;
+        x[b * x_bs + (int64_t)(2 * c + 1) * HW + o] = (l - v) * CWFA_INV_SQRT2_F;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)ssum, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], -tot);
+    }
+}
+
+__global__ __launch_bounds__(256) void chain_fwd_rows_kernel(const float* __restrict__ x, float* __restrict__ low,
+                                                             float* __restrict__ zout, cwfa_chain ch,
+                                                             const int64_t* __restrict__ final_perm, int C, int H, int W,
+                                                             int64_t x_bs, int64_t low_bs, int64_t z_bs,
+                                                             double* __restrict__ logdet, double* __restrict__ sumsq) {
+    extern __shared__ float rows[];          // [stage][2][W]: e = exp(s), t      + [W] detail row at the source
+    __shared__ double red[16];
+    const int b = blockIdx.z, c = blockIdx.y, h = blockIdx.x;
+    const int64_t HW = (int64_t)H * W;
+    RowPos q[CWFA_CHAIN_MAX], src = row_gather(RowPos{c, h}, final_perm, 1);
+#pragma unroll
+    for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+        if (k < ch.n_stages) {
+            q[k] = src;
+            src = row_gather(src, ch.stage[k].perm, ch.stage[k].perm_axis);
+        }
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+        if (k < ch.n_stages) {
+            const int64_t off = ((int64_t)q[k].c * H + q[k].h) * W;
+            for (int w = threadIdx.x; w < W; w += blockDim.x) {
+                float s, t;
+                stage_st(ch.stage[k], b, off + w, s, t);
+                ssum += s;
+                rows[(2 * k) * W + w] = expf(s);
+                rows[(2 * k + 1) * W + w] = t;
+            }
+        }
+    float* drow = rows + 2 * ch.n_stages * W;
+    {   // detail (hi) row where this block's values start, and the low-pass row at the block's own position
+        const int64_t so = (int64_t)src.h * W, oo = (int64_t)h * W;
+        const float* xe = x + b * x_bs + (int64_t)(2 * src.c) * HW + so;
+        const float* xs = x + b * x_bs + (int64_t)(2 * c) * HW + oo;
+        for (int w = threadIdx.x; w < W; w += blockDim.x) {
+            drow[w] = (xe[w] - xe[HW + w]) * CWFA_INV_SQRT2_F;
+            low[b * low_bs + (int64_t)c * HW + oo + w] = (xs[w] + xs[HW + w]) * CWFA_INV_SQRT2_F;
+        }
+    }
+    __syncthreads();
+    double sq = 0.0;
+    for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        int wq[CWFA_CHAIN_MAX], w0 = w;
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+            if (k < ch.n_stages) {
+                wq[k] = w0;
+                if (ch.stage[k].perm && ch.stage[k].perm_axis == 3) w0 = (int)ch.stage[k].perm[w0];
+            }
+        float v = drow[w0];
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+            if (k < ch.n_stages) v = rows[(2 * k) * W + wq[k]] * v + rows[(2 * k + 1) * W + wq[k]];
+        zout[b * z_bs + (int64_t)c * HW + (int64_t)h * W + w] = v;
+        sq += (double)v * (double)v;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)ssum, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], tot);
+    }
+    if (sumsq) {
+        const double tot = cwfa_block_sum(sq, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq, tot);
+    }
+}
+
+// rows variant usable?  (LDS budget, grid limits)
+static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds) {
+    *lds = (size_t)(2 * ch->n_stages + 1) * W * sizeof(float);
+    return *lds <= 60 * 1024 && C <= 65535 && B <= 65535 && W >= 64;
+}
+
 static int check_chain(const char* name, const cwfa_chain* ch) {
     CWFA_REQUIRE(ch, CWFA_E_INVAL, "%s: null chain", name);
     CWFA_REQUIRE(ch->n_stages >= 0 && ch->n_stages <= CWFA_CHAIN_MAX, CWFA_E_INVAL, "%s: %d stages (max %d)", name,
@@ -499,6 +645,13 @@ extern "C" int cwfa_chain_inv_f32(const float* z, const float* low, float* x, co
     if (rc) return rc;
     const int64_t n = (int64_t)C * H * W;
     if (B == 0 || n == 0) return CWFA_OK;
+    size_t lds;
+    if (chain_rows_ok(ch, C, H, W, B, &lds)) {
+        hipLaunchKernelGGL(chain_inv_rows_kernel, dim3(H, C, B), dim3(256), lds, (hipStream_t)stream, z, low, x, *ch, C, H, W,
+                           z_bs, low_bs, x_bs, logdet);
+        CWFA_LAUNCH_CHECK("cwfa_chain_inv_f32");
+        return CWFA_OK;
+    }
     dim3 grid((unsigned)((n + 255) / 256), B);
     hipLaunchKernelGGL(chain_inv_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, low, x, *ch, C, H, W, z_bs, low_bs, x_bs,
                        logdet);
@@ -515,6 +668,13 @@ extern "C" int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cw
     if (rc) return rc;
     const int64_t n = (int64_t)C * H * W;
     if (B == 0 || n == 0) return CWFA_OK;
+    size_t lds;
+    if (chain_rows_ok(ch, C, H, W, B, &lds)) {
+        hipLaunchKernelGGL(chain_fwd_rows_kernel, dim3(H, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z, *ch, final_perm,
+                           C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
+        CWFA_LAUNCH_CHECK("cwfa_chain_fwd_f32");
+        return CWFA_OK;
+    }
     dim3 grid((unsigned)((n + 255) / 256), B);
     hipLaunchKernelGGL(chain_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, low, z, *ch, final_perm, C, H, W, x_bs,
                        low_bs, z_bs, logdet, sumsq);

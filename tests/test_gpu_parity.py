@@ -467,6 +467,45 @@ def test_lrnn_small_and_full_golden():
     assert_close(enc(x_full.cuda())[-1][:, :, ::23, ::29], ff["y_nomean_sub"], TOL, "full, no mean volume")
 
 
+@pytest.mark.parametrize("hw", [(40, 96), (24, 300)])
+def test_cat_step_row_staged_chain_vs_oracle(hw):
+    """Wide images take the row-staged chain kernels (W >= 64): compare a CAT step, both directions, with the oracle."""
+    from cwfa_amd import CWFA, networks as N
+    from oracle import cwfa_oracle as O
+    H, W = hw
+    torch.manual_seed(3)
+    np.random.seed(3)
+    cn, inns = N.conditional_wavelet_flow([12, H, W], [1, 29, H, W], N.wavelet_flow_subnetwork2D,
+                                          lambda: N.cond_network(29, 6, 1, 3, [], 4), n_internal_ch=8, n_down_steps=1,
+                                          use_permutations=True, block_type="CAT", n_blocks=4)
+    g = inns[0].eval()
+    with torch.no_grad():
+        for p_ in g.parameters():
+            if p_.requires_grad:
+                p_.add_(0.05 * torch.randn(p_.shape))
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(g.module_list) if hasattr(m, "perm")}
+    gen = torch.Generator().manual_seed(W)
+    x = torch.randn(2, 12, H, W, generator=gen)
+    c = [torch.randn(2, 6, H, W, generator=gen), 0.3 * torch.randn(2, 6, H, W, generator=gen)]
+    (z_ref, low_ref), j_ref = O.flow_step(sd, x, c, False, axes)
+    x_ref, jr_ref = O.flow_step(sd, (z_ref, low_ref), c, True, axes)
+    g = g.cuda()
+    cc = [t.cuda() for t in c]
+    sumsq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    (z, low), j = g(x.cuda(), c=cc, sumsq=sumsq)
+    assert_close(z, z_ref, TOL, "z")
+    assert torch.equal(low.cpu(), low_ref)
+    assert_close(j, j_ref, TOL, "logdet")
+    assert abs(float(sumsq) - float(z_ref.double().pow(2).sum())) <= 1e-5 * float(z_ref.double().pow(2).sum())
+    xr, jr = g([z_ref.cuda(), low_ref.cuda()], c=cc, rev=True)
+    assert_close(xr, x_ref, TOL, "x_rev")
+    assert_close(jr, jr_ref, TOL, "logdet rev")
+    x0, j0 = g([None, low_ref.cuda()], c=cc, rev=True, jac=False)
+    assert j0 is None
+    assert_close(x0, O.flow_step(sd, (torch.zeros_like(z_ref), low_ref), c, True, axes)[0], TOL, "x_rev z=0")
+
+
 def test_full_size_step_roundtrip():
     """Config-3 finest step (C=48, 512x512): forward then inverse recovers x; log-dets are antisymmetric."""
     from cwfa_amd import CWFA
