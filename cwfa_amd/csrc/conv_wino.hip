@@ -192,22 +192,32 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     // would stage at the same time and leave the matrix pipe idle ~28 % of the chunk; staggered, one of them always has
     // MFMAs to issue (MI355X_MICROARCH "Two waves per SIMD", item 9).
     const bool early = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= C::NTHREADS / 2;
+    // The MFMA block is software-pipelined BY HAND: the LDS operands of k-step s+DEPTH are read while the MFMAs of step
+    // s issue, and every step is fenced for the instruction scheduler.  With compiler placement the reads landed right
+    // before their MFMAs (register pressure), a wave on its own then sustained only ~2/3 of the matrix-pipe rate, and
+    // that is exactly the situation whenever its SIMD partner is staging the next chunk (ablation: staging cost 17 %).
+    constexpr int NSTEP = 12 * (C::CK / 2), DEPTH = 2;
     auto mfmas = [&](int cur) {
         const float* ulane = ulane0 + cur * C::BUF;
         const float* vlane = vlane0 + cur * C::BUF;
+        float bq[DEPTH + 1], aq[DEPTH + 1][C::MT];
+        auto ld = [&](int s, int slot) {
+            const int kk = s % (C::CK / 2), xi = (s / (C::CK / 2)) % 4, ky = s / (4 * (C::CK / 2));
+            bq[slot] = vlane[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int m = 0; m < C::MT; ++m) aq[slot][m] = ulane[((ky * 4 + xi) * C::CK + 2 * kk) * C::CT + m * 32];
+        };
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
+        for (int s = 0; s < DEPTH; ++s) ld(s, s);
 #pragma unroll
-                for (int kk = 0; kk < C::CK / 2; ++kk) {
-                    const float bv = vlane[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
+        for (int s = 0; s < NSTEP; ++s) {
+            const int xi = (s / (C::CK / 2)) % 4;
+            if (s + DEPTH < NSTEP) ld(s + DEPTH, (s + DEPTH) % (DEPTH + 1));
 #pragma unroll
-                    for (int m = 0; m < C::MT; ++m) {
-                        const float a = ulane[((ky * 4 + xi) * C::CK + 2 * kk) * C::CT + m * 32];
-                        acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[m][xi], 0, 0, 0);
-                    }
-                }
+            for (int m = 0; m < C::MT; ++m)
+                acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % (DEPTH + 1)][m], bq[s % (DEPTH + 1)], acc[m][xi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     prefetch(0);
     commit(0, 0);
@@ -216,12 +226,25 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < p.nchunks;
+#ifdef CWFA_EXP_NOSTAGE     // experiment: no staging inside the loop (wrong results; isolates MFMA + LDS reads + barrier)
+        mfmas(cur);
+        (void)more; (void)early;
+#else
+#ifndef CWFA_EXP_NOCOMMIT
         if (early && more) commit(chunk + 1, cur ^ 1);
+#endif
         const int pf = early ? chunk + 2 : chunk + 1;
+#ifndef CWFA_EXP_NOPREFETCH
         if (pf < p.nchunks) prefetch(pf);
+#endif
         mfmas(cur);                                      // ONE copy of the MFMA block (two copies spilled)
+#ifndef CWFA_EXP_NOCOMMIT
         if (!early && more) commit(chunk + 1, cur ^ 1);
+#endif
+#endif
+#ifndef CWFA_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 }
 
