@@ -111,6 +111,168 @@ __global__ __launch_bounds__(256) void conv3d_1k1_kernel(const float* __restrict
     }
 }
 
+
+// ---- matrix-core version (K <= 32) ---------------------------------------------------------------------------------
+// Both convolutions as 32x32x2 fp32 MFMA GEMMs over one row of 32 hidden voxels (lanes = w):
+//   conv1:  hidden[k][w] = b1[k] + sum_tap w1[k][tap] * x[tap-shifted w]      M = k (32), N = 32 voxels, K = 27 taps (14 MFMAs)
+//   conv2:  P[tap][w]    = sum_k w2[k][tap] * hidden[k][w]                    M = tap (27 of 32), K = 32 channels (16 MFMAs;
+//           conv1's accumulator registers ARE conv2's B operand: register r of lane (w, kh) holds channel rc(r)+4kh,
+//           which is the k-pair layout the instruction wants)
+// and P[tap][w] is the contribution of hidden voxel (d',h',w) to output voxel (d'-dd, h'-dh, w-dw): it is scattered with
+// ds_add_f32 into a per-wave private copy of the output tile (fixed program order => deterministic), the four copies
+// are summed at the end.  Block = 6 x 8 x 30 output voxels; the +1 hidden halo makes rows exactly 32 wide.
+struct C3M {
+    static constexpr int DT = 6, HT = 8, WT = 30, NTHREADS = 256, NWAVES = 4;
+    static constexpr int XD = DT + 4, XH = HT + 4, XW = 36;     // staged input (origin -2), 34 used columns
+    static constexpr int HD = DT + 2, HH = HT + 2;               // hidden rows (origin -1), 32 columns
+    static constexpr int XS = XD * XH * XW, OS = DT * HT * 32;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// batch of tap t in the scatter (found by exhaustive search: 10 of the 12 two-tap registers keep both halves together)
+__host__ __device__ constexpr int c3m_batch(int t) {
+    constexpr int F[9] = {0, 2, 1, 2, 1, 1, 2, 1, 0};
+    return t < 27 ? ((t / 3) % 3 + F[t % 3 + 3 * (t / 9)]) % 3 : -1;
+}
+
+__global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ alpha_p,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ y, int D, int H, int W, int K,
+                                                              int tiles_w) {
+    typedef C3M C;
+    __shared__ float Xs[C::XS];
+    __shared__ float Os[C::NWAVES * C::OS + C::NTHREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wl = lane & 31, kh = lane >> 5;
+    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    const int d0 = blockIdx.y * C::DT, h0 = th * C::HT, w0 = tw * C::WT, b = blockIdx.z;
+    const int64_t HW = (int64_t)H * W;
+    const float* xb = x + (int64_t)b * D * HW;
+    const float alpha = *alpha_p;
+
+    {   // all loads of the haloed tile in flight together (clamped address, masked value), then the LDS writes
+        constexpr int NI = (C::XS + C::NTHREADS - 1) / C::NTHREADS;
+        float v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = min(tid + i * C::NTHREADS, C::XS - 1);
+            const int dd = e / (C::XH * C::XW), rem = e % (C::XH * C::XW), hh = rem / C::XW, ww = rem % C::XW;
+            const int gd = d0 + dd - 2, gh = h0 + hh - 2, gw = w0 + ww - 2;
+            const bool in = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+            const float t = xb[(int64_t)min(max(gd, 0), D - 1) * HW + (int64_t)min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)];
+            v[i] = in ? t : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tid + i * C::NTHREADS < C::XS) Xs[tid + i * C::NTHREADS] = v[i];
+    }
+    for (int e = tid; e < C::NWAVES * C::OS; e += C::NTHREADS) Os[e] = 0.f;
+
+    // operand panels, resident in registers for the whole block.  conv1's bias rides on the unused 28th tap
+    // (MFMA 13, k-slot 1: A = b1[k], B = 1).  pk[r] = where accumulator register r of this lane scatters to, relative
+    // to the hidden row, plus (bits 16..) which bit of the per-row validity mask guards it (31 = never).
+    float a1[14], a2[16];
+    int toff[14], pk[16];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int tap = 2 * j + kh;
+        const int kk = min(wl, K - 1);
+        const float wv = w1[kk * 27 + min(tap, 26)], bv = b1[kk];
+        a1[j] = wl < K ? (tap < 27 ? wv : bv) : 0.f;
+        const int t = tap < 27 ? tap : 0;
+        toff[j] = ((t % 3) * C::XH + t / 9) * C::XW + (t / 3) % 3;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float w2v = w2[min(k, K - 1) * 27 + min(wl, 26)];
+        a2[r] = (k < K && wl < 27) ? w2v : 0.f;
+        const int tap = k;                                     // same index formula: row of P held by (r, kh)
+        const int dd = tap % 3, dw = (tap / 3) % 3, dh = tap / 9, ow = wl - dw;
+        const bool valid = tap < 27 && ow >= 0 && ow < C::WT;
+        pk[r] = ((-dd * C::HT - dh) * 32 + ow + 1024) | ((valid ? dd + 3 * dh : 31) << 16);
+    }
+    __syncthreads();
+
+    float* Ow = Os + wave * C::OS;
+    const int dummy = C::NWAVES * C::OS + tid;                 // per-lane sink for masked-off contributions
+    const int gw = w0 - 1 + wl;
+    const bool in_w = gw >= 0 && gw < W;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 Pp = zero16;          // conv2 products of the previous row, scattered under the next row's conv1 MFMAs
+    int pbase = 0, pmask = 0;
+    // LDS read-modify-write in three alias-free batches: two contributions can only meet in one output voxel when their
+    // taps share (dd, dh) and differ in dw, so a batch takes at most one tap of each (dd, dh) triple (c3m_batch) and its
+    // reads can all be in flight before its writes.  Lanes whose half is not in the batch (or masked off) hit the sink.
+    auto scatter = [&](const f32x16& P, int base, int mask) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float old[15];
+            int at[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                const int t0 = (r & 3) + 8 * (r >> 2);
+                const bool h0 = c3m_batch(t0) == c, h1 = c3m_batch(t0 + 4) == c;
+                if (!h0 && !h1) continue;
+                const bool mine = kh ? h1 : h0;
+                at[r] = (mine && ((mask >> (pk[r] >> 16)) & 1)) ? base + (pk[r] & 0xffff) : dummy;
+                old[r] = Os[at[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                const int t0 = (r & 3) + 8 * (r >> 2);
+                if (c3m_batch(t0) != c && c3m_batch(t0 + 4) != c) continue;
+                Os[at[r]] = old[r] + P[r];
+            }
+        }
+    };
+    for (int row = wave; row < C::HD * C::HH; row += C::NWAVES) {
+        const int dp = row / C::HH, hp = row % C::HH;
+        const int gd = d0 - 1 + dp, gh = h0 - 1 + hp;
+        if (gd < 0 || gd >= D || gh < 0 || gh >= H) continue;      // hidden row is conv2's zero padding (wave-uniform)
+        const float* xr = Xs + (dp * C::XH + hp) * C::XW + wl;
+        float xv[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) xv[j] = xr[toff[j]];
+        xv[13] = kh ? 1.f : xv[13];
+        f32x16 hid = zero16;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], xv[j], hid, 0, 0, 0);
+        scatter(Pp, pbase, pmask);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = hid[r];
+            v = v > 0.f ? v : alpha * v;
+            hid[r] = in_w ? v : 0.f;
+        }
+        f32x16 P = zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], hid[r], P, 0, 0, 0);
+        Pp = P;
+        pbase = wave * C::OS + (dp * C::HT + hp) * 32 - 1024;
+        int m = 0;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd)
+                if ((unsigned)(dp - dd) < (unsigned)C::DT && (unsigned)(hp - dh) < (unsigned)C::HT) m |= 1 << (dd + 3 * dh);
+        pmask = m;
+    }
+    scatter(Pp, pbase, pmask);
+    (void)Ow;
+    __syncthreads();
+    const float bb = b2[0];
+    for (int e = tid; e < C::OS; e += C::NTHREADS) {
+        const int ow = e & 31, oh = (e >> 5) % C::HT, od = e / (32 * C::HT);
+        const int gdo = d0 + od, gho = h0 + oh, gwo = w0 + ow;
+        if (ow < C::WT && gdo < D && gho < H && gwo < W)
+            y[(int64_t)b * D * HW + (int64_t)gdo * HW + (int64_t)gho * W + gwo] =
+                ((Os[e] + Os[C::OS + e]) + (Os[2 * C::OS + e] + Os[3 * C::OS + e])) + bb;
+    }
+}
+
 }  // namespace
 
 extern "C" int cwfa_conv3d_1k1_f32(const float* x, const float* w1, const float* b1, const float* alpha, const float* w2,
@@ -119,6 +281,14 @@ extern "C" int cwfa_conv3d_1k1_f32(const float* x, const float* w1, const float*
     CWFA_REQUIRE(B >= 0 && D >= 0 && H >= 0 && W >= 0 && K > 0, CWFA_E_INVAL, "cwfa_conv3d_1k1_f32: bad size");
     CWFA_REQUIRE(x != y, CWFA_E_INVAL, "cwfa_conv3d_1k1_f32: in-place not supported");
     if (B == 0 || D == 0 || H == 0 || W == 0) return CWFA_OK;
+    if (K <= 32) {
+        const int tw = (W + C3M::WT - 1) / C3M::WT, th = (H + C3M::HT - 1) / C3M::HT, td = (D + C3M::DT - 1) / C3M::DT;
+        CWFA_REQUIRE(td <= 65535 && B <= 65535, CWFA_E_SHAPE, "cwfa_conv3d_1k1_f32: grid too large");
+        hipLaunchKernelGGL(conv3d_1k1_mfma_kernel, dim3(tw * th, td, B), dim3(256), 0, (hipStream_t)stream, x, w1, b1, alpha,
+                           w2, b2, y, D, H, W, K, tw);
+        CWFA_LAUNCH_CHECK("cwfa_conv3d_1k1_f32");
+        return CWFA_OK;
+    }
     const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
     const bool d6 = D % 6 == 0;
     const int DT = d6 ? 6 : 8;

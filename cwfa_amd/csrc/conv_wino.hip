@@ -15,12 +15,25 @@
 // and U[3][4][CK][CT].  The output transform runs on the accumulators in registers; a lane then owns two adjacent pixels
 // and stores them as one 8-byte word (256 B contiguous per half-wave).
 #include "conv_internal.h"
+#include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+
+template <int K>
+using sc_int = std::integral_constant<int, K>;
+template <class F, int... S>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, S...>) {
+    (f(sc_int<S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <int CK_, int MT_, int WM_, int WN_>
 struct WCfg {
@@ -50,6 +63,10 @@ struct WParams {
     const float* w1x1;
     const float* b1x1;
 };
+
+#ifdef CWFA_EXP_STAMP
+__device__ long long g_stamps[8 * 40 * 5];
+#endif
 
 struct WTile {
     int wm, wn, kh, l31, ct, b, row0, col0;
@@ -81,99 +98,107 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     const int64_t HW = (int64_t)p.H * p.W;
     constexpr int RSTEP = C::NTHREADS / 32;
 
-    // staging map: this thread always handles tile column tt = tid % 32; element i covers (channel ci[i], tile row ri[i])
+    // Staging map: this thread always handles tile column tt = tid % 32; element i covers (channel cloc(i), tile row r(i)).
+    // Global reads go through buffer descriptors (one per tensor, per batch sample): the per-lane part of an address is a
+    // 32-bit byte offset computed ONCE (voff), the per-chunk part is the scalar soffset, and everything that is padding --
+    // rows/columns outside the image, channels >= Cin -- is an out-of-range offset that the hardware range check turns
+    // into 0.0 without any vector instruction (cwfa_wino_conv checks the slice is < 2 GiB so OOB + soffset cannot wrap).
+    constexpr unsigned OOB = 0x80000000u;
     const int tt = tid & 31;
-    int coff[4];
-    unsigned cmask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int gc = t.col0 + 2 * tt - 1 + j;
-        const bool ok = gc >= 0 && gc < p.W;
-        cmask |= ok ? (1u << j) : 0u;
-        coff[j] = ok ? gc : 0;
-    }
-    int roff[C::VPT], cloc[C::VPT], vdst[C::VPT];
-    unsigned rmask = 0;
+    unsigned voff[C::VPT][4], vdst[C::VPT], cl4[PRO ? C::VPT : 1];
+    unsigned long long rowok[PRO ? C::VPT : 1], colok[PRO ? 4 : 1];     // lane masks (SGPR pairs), load-side affine only
 #pragma unroll
     for (int i = 0; i < C::VPT; ++i) {
         const int rc = (tid >> 5) + i * RSTEP;
         const int r = rc % C::XR, c = rc / C::XR;
         const int gr = t.row0 + r - 1;
-        const bool ok = gr >= 0 && gr < p.H;
-        rmask |= ok ? (1u << i) : 0u;
-        cloc[i] = c;
-        roff[i] = (ok ? gr : 0) * p.W;
+        const bool rok = gr >= 0 && gr < p.H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gc = t.col0 + 2 * tt - 1 + j;
+            const bool ok = rok && gc >= 0 && gc < p.W;
+            voff[i][j] = ok ? (unsigned)((c * HW + (int64_t)gr * p.W + gc) * 4) : OOB;
+            if (PRO && i == 0) colok[j] = __builtin_amdgcn_ballot_w64(gc >= 0 && gc < p.W);
+        }
         vdst[i] = (c * C::XR + r) * 32 + tt;
+        if constexpr (PRO) {
+            cl4[i] = c * 4;
+            rowok[i] = __builtin_amdgcn_ballot_w64(rok);
+        }
     }
-    const float* xb = p.x + (int64_t)t.b * p.x_bs;
-    const float* ab = (PRO && p.o.in_add) ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : nullptr;
-    const float* wb = p.wp + (int64_t)t.ct * p.nchunks * C::US;
-    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && ab != nullptr;
-    const float* scb = has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : nullptr;
-    const float* shb = has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : nullptr;
+    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && p.o.in_add != nullptr;
+    const int xbytes = (int)((int64_t)p.Cin * HW * 4);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, xbytes, 0x00020000);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_add ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : p.x), 0, has_add ? xbytes : 0, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : p.x), 0, has_aff ? p.Cin * 4 : 0, 0x00020000);
+    const auto rsh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : p.x), 0, has_aff ? p.Cin * 4 : 0, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp + (int64_t)t.ct * p.nchunks * C::US), 0,
+                                                      p.nchunks * C::US * 4, 0x00020000);
+    const int chunk_bytes = (int)(C::CK * HW * 4);
+    const unsigned uoff = tid * 16;
+    auto ldf = [](decltype(rx) r, unsigned vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
 
     constexpr int NP = PRO ? C::VPT : 1;
     f32x4 dr[C::VPT], ar[NP];
     float sr[NP], hr[NP];
     f32x4 ur[C::UPT];
 
-    // all loads unconditional (clamped addresses), nothing waits here; masking / affine / transform happen at commit
-    auto prefetch = [&](int chunk) {
-        const int c0 = chunk * C::CK;
+    // Staging is cut into ITEMS (one V element = 4 inputs -> 4 Winograd components, or one 16-byte piece of the U panel).
+    // Nothing waits on a load where it is issued; the load-side affine, its masking and the input transform happen when
+    // the item is stored to LDS, a whole chunk later.
+    auto load_v = [&](int i, int chunk) {
+        const int so = chunk * chunk_bytes;
 #pragma unroll
-        for (int i = 0; i < C::VPT; ++i) {
-            int ci = c0 + cloc[i];
-            ci = ci < p.Cin ? ci : p.Cin - 1;
-            const float* src = xb + (int64_t)ci * HW + roff[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dr[i][j] = src[coff[j]];
-            if constexpr (PRO) {
-                if (has_aff) {
-                    sr[i] = scb[ci];
-                    hr[i] = shb[ci];
-                }
-                if (has_add) {
-                    const float* asrc = ab + (int64_t)ci * HW + roff[i];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ar[i][j] = asrc[coff[j]];
-                }
+        for (int j = 0; j < 4; ++j) dr[i][j] = ldf(rx, voff[i][j], so);
+        if constexpr (PRO) {
+            if (has_aff) {
+                sr[i] = ldf(rsc, cl4[i], chunk * C::CK * 4);
+                hr[i] = ldf(rsh, cl4[i], chunk * C::CK * 4);
             }
-        }
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(wb + (int64_t)chunk * C::US);
+            if (has_add) {
 #pragma unroll
-        for (int i = 0; i < C::UPT; ++i) {
-            const int e = tid + i * C::NTHREADS;
-            ur[i] = w4[e < C::US / 4 ? e : 0];
+                for (int j = 0; j < 4; ++j) ar[i][j] = ldf(ra, voff[i][j], so);
+            }
         }
     };
-    auto commit = [&](int chunk, int buf) {
-        const int c0 = chunk * C::CK;
-        float* Vb = Vs + buf * C::BUF;
-        float* Ub = Us + buf * C::BUF;
+    auto load_u = [&](int i, int chunk) {
+        static_assert(C::US / 4 == C::UPT * C::NTHREADS, "U panel is a whole number of 16-byte pieces per thread");
+        ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, uoff, (chunk * C::US + i * C::NTHREADS * 4) * 4, 0));
+    };
+    auto store_v = [&](int i, int buf) {
+        float d[4];
 #pragma unroll
-        for (int i = 0; i < C::VPT; ++i) {
-            const bool rc_ok = ((rmask >> i) & 1u) && (c0 + cloc[i] < p.Cin);
-            float d[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = dr[i][j];
-                if constexpr (PRO) {
-                    if (has_aff) v = v * sr[i] + hr[i];
-                    if (has_add) v += ar[i][j];
+        for (int j = 0; j < 4; ++j) {
+            float v = dr[i][j];
+            if constexpr (PRO) {
+                if (has_aff) {
+                    v = v * sr[i] + hr[i];                              // padding must be zero AFTER the affine
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v) : "v"(v), "s"(rowok[i] & colok[j]));
                 }
-                d[j] = (rc_ok && ((cmask >> j) & 1u)) ? v : 0.f;         // zero padding AFTER the load-side affine
+                if (has_add) v += ar[i][j];
             }
-            float* dst = Vb + vdst[i];
-            dst[0 * C::VPLANE] = d[0] - d[2];
-            dst[1 * C::VPLANE] = d[1] + d[2];
-            dst[2 * C::VPLANE] = d[2] - d[1];
-            dst[3 * C::VPLANE] = d[1] - d[3];
+            d[j] = v;
         }
-#pragma unroll
-        for (int i = 0; i < C::UPT; ++i) {
-            const int e = tid + i * C::NTHREADS;
-            if (e < C::US / 4) reinterpret_cast<f32x4*>(Ub)[e] = ur[i];
-        }
+        float* dst = Vs + buf * C::BUF + vdst[i];
+        dst[0 * C::VPLANE] = d[0] - d[2];
+        dst[1 * C::VPLANE] = d[1] + d[2];
+        dst[2 * C::VPLANE] = d[2] - d[1];
+        dst[3 * C::VPLANE] = d[1] - d[3];
+    };
+    auto store_u = [&](int i, int buf) { reinterpret_cast<f32x4*>(Us + buf * C::BUF)[tid + i * C::NTHREADS] = ur[i]; };
+    constexpr int NITEM = C::VPT + C::UPT;
+    auto load_item = [&](auto kc, int chunk) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < C::VPT) load_v(k, chunk);
+        else load_u(k - C::VPT, chunk);
+    };
+    auto store_item = [&](auto kc, int buf) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < C::VPT) store_v(k, buf);
+        else store_u(k - C::VPT, buf);
     };
 
 #pragma unroll
@@ -183,68 +208,71 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][xi][r] = 0.f;
 
-    const float* ulane0 = Us + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
+    static_assert(C::MT == 2, "U panel layout interleaves exactly two m-tiles");
+    const float* ulane0 = Us + t.kh * C::CT + t.wm * 64 + 2 * t.l31;
     const float* vlane0 = Vs + (t.kh * C::XR + t.wn) * 32 + t.l31;
 
-    // Two LDS buffers, ONE barrier per chunk, and a STAGGER between the two waves that share a SIMD (waves w and w+4 of
-    // a 512-thread block): the late half does [MFMAs of chunk c, then stage chunk c+1], the early half [stage chunk c+1
-    // (its global loads were issued a whole chunk earlier), then MFMAs of chunk c].  Run in lockstep, both waves of a SIMD
-    // would stage at the same time and leave the matrix pipe idle ~28 % of the chunk; staggered, one of them always has
-    // MFMAs to issue (MI355X_MICROARCH "Two waves per SIMD", item 9).
-    const bool early = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= C::NTHREADS / 2;
-    // The MFMA block is software-pipelined BY HAND: the LDS operands of k-step s+DEPTH are read while the MFMAs of step
-    // s issue, and every step is fenced for the instruction scheduler.  With compiler placement the reads landed right
-    // before their MFMAs (register pressure), a wave on its own then sustained only ~2/3 of the matrix-pipe rate, and
-    // that is exactly the situation whenever its SIMD partner is staging the next chunk (ablation: staging cost 17 %).
-    constexpr int NSTEP = 12 * (C::CK / 2), DEPTH = 2;
-    auto mfmas = [&](int cur) {
+    // Schedule.  Two LDS buffers, ONE barrier per chunk.  On gfx950 the fp32 MFMA and the vector ALU do not co-execute
+    // (SQ_VALU_MFMA_COEXEC_CYCLES = 0) and a wave that has its next MFMA ready STARVES its SIMD partner's vector
+    // instructions completely (tools/probe/mfma_partner.hip: partner VALU makes no progress until the chain ends), so
+    // "one wave stages while the other computes" does not overlap anything: staging VALU only runs in the gaps of the
+    // partner's MFMA stream.  Vector work placed INSIDE a wave's own MFMA stream costs its 4 issue cycles and nothing
+    // else (tools/probe/mfma_valu.hip: 64 + ~3.2 cycles per VALU per MFMA).  So every wave runs the same stream: the 48
+    // k-steps of chunk c, and after every few steps ONE staging item: store item k of chunk c+1 to the other LDS buffer
+    // (its loads were issued one chunk ago), then issue its loads for chunk c+2 into the registers just freed.
+    // The LDS operands of k-step s+DEPTH are read while the MFMAs of step s issue; every step is fenced for the scheduler.
+    constexpr int NSTEP = 12 * (C::CK / 2), DEPTH = 2, SLOT0 = 1, SLOTD = (NSTEP - 2) / NITEM;
+    auto mfmas = [&](int cur, int chunk, bool more, bool pf) {
         const float* ulane = ulane0 + cur * C::BUF;
         const float* vlane = vlane0 + cur * C::BUF;
         float bq[DEPTH + 1], aq[DEPTH + 1][C::MT];
         auto ld = [&](int s, int slot) {
             const int kk = s % (C::CK / 2), xi = (s / (C::CK / 2)) % 4, ky = s / (4 * (C::CK / 2));
             bq[slot] = vlane[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
-#pragma unroll
-            for (int m = 0; m < C::MT; ++m) aq[slot][m] = ulane[((ky * 4 + xi) * C::CK + 2 * kk) * C::CT + m * 32];
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(ulane + ((ky * 4 + xi) * C::CK + 2 * kk) * C::CT);
+            aq[slot][0] = a2[0];
+            aq[slot][1] = a2[1];
         };
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) ld(s, s);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            const int xi = (s / (C::CK / 2)) % 4;
-            if (s + DEPTH < NSTEP) ld(s + DEPTH, (s + DEPTH) % (DEPTH + 1));
+        // compile-time step index: the staging item (and its register arrays) must resolve statically, whatever the unroller thinks
+        static_for<NSTEP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, xi = (s / (C::CK / 2)) % 4;
+            if constexpr (s + DEPTH < NSTEP) ld(s + DEPTH, (s + DEPTH) % (DEPTH + 1));
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
                 acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % (DEPTH + 1)][m], bq[s % (DEPTH + 1)], acc[m][xi], 0, 0, 0);
+#ifndef CWFA_EXP_NOSTAGE
+            if constexpr (s >= SLOT0 && (s - SLOT0) % SLOTD == 0 && (s - SLOT0) / SLOTD < NITEM) {
+                constexpr int k = (s - SLOT0) / SLOTD;
+                if (more) store_item(sc_int<k>{}, cur ^ 1);
+                if (pf) load_item(sc_int<k>{}, chunk + 2);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
-    prefetch(0);
-    commit(0, 0);
-    if (early && 1 < p.nchunks) prefetch(1);
+#ifdef CWFA_EXP_STAMP
+    const bool stamp_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0;
+#define STAMP(k) do { if (stamp_on && chunk < 40) g_stamps[((threadIdx.x >> 6) * 40 + chunk) * 5 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k)
+#endif
+    static_for<NITEM>([&](auto kc) { load_item(kc, 0); });
+    static_for<NITEM>([&](auto kc) {
+        store_item(kc, 0);
+        if (1 < p.nchunks) load_item(kc, 1);
+    });
     __syncthreads();
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int cur = chunk & 1;
-        const bool more = chunk + 1 < p.nchunks;
-#ifdef CWFA_EXP_NOSTAGE     // experiment: no staging inside the loop (wrong results; isolates MFMA + LDS reads + barrier)
-        mfmas(cur);
-        (void)more; (void)early;
-#else
-#ifndef CWFA_EXP_NOCOMMIT
-        if (early && more) commit(chunk + 1, cur ^ 1);
-#endif
-        const int pf = early ? chunk + 2 : chunk + 1;
-#ifndef CWFA_EXP_NOPREFETCH
-        if (pf < p.nchunks) prefetch(pf);
-#endif
-        mfmas(cur);                                      // ONE copy of the MFMA block (two copies spilled)
-#ifndef CWFA_EXP_NOCOMMIT
-        if (!early && more) commit(chunk + 1, cur ^ 1);
-#endif
-#endif
-#ifndef CWFA_EXP_NOBARRIER
+        STAMP(0);
+        STAMP(1);
+        mfmas(cur, chunk, chunk + 1 < p.nchunks, chunk + 2 < p.nchunks);
+        STAMP(2);
+        STAMP(3);
         __syncthreads();
-#endif
+        STAMP(4);
     }
 }
 
@@ -360,7 +388,9 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     const int ky = (int)((i / ((int64_t)CT * CK * 4)) % 3);
     const int chunk = (int)((i / ((int64_t)CT * CK * 12)) % nchunks);
     const int ctile = (int)(i / ((int64_t)CT * CK * 12 * nchunks));
-    const int co = ctile * CT + col, ci = chunk * CK + ck;
+    // within a panel the two 32-channel m-tiles of a wave are interleaved (position 64g + 2i + m <-> channel 64g + 32m + i)
+    // so a lane fetches its A operands for both tiles with ONE ds_read_b64
+    const int co = ctile * CT + (col & ~63) + (col & 1) * 32 + ((col & 63) >> 1), ci = chunk * CK + ck;
     float v = 0.f;
     if (co < Cout && ci < Cin) {
         const float* g = w + (((int64_t)co * Cin + ci) * 3 + ky) * 3;
@@ -500,6 +530,8 @@ int wlaunch(WParams p, hipStream_t stream) {
     const int ctiles = (p.Cout + C::CT - 1) / C::CT;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
                  "cwfa_conv2d_f32: grid too large");
+    CWFA_REQUIRE((int64_t)(p.Cin + C::CK) * p.H * p.W * 4 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv2d_f32: one sample's input must stay below 2 GiB (32-bit buffer offsets)");
     constexpr int LDS = EPI == WEPI_GENERIC && C::LDS_BYTES < C::NTHREADS * 128 ? C::NTHREADS * 128 : C::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -590,6 +622,8 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
     p.tiles_y = (H + C::TR - 1) / C::TR;
     p.nchunks = 64 / C::CK;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_subnet_layer_f32: grid too large");
+    CWFA_REQUIRE((int64_t)(64 + C::CK) * H * W * 4 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_subnet_layer_f32: one sample's input must stay below 2 GiB (32-bit buffer offsets)");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_layer_kernel),
@@ -605,3 +639,9 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_f32 (winograd)");
     return CWFA_OK;
 }
+
+#ifdef CWFA_EXP_STAMP
+extern "C" int cwfa_debug_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
+}
+#endif

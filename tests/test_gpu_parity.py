@@ -225,7 +225,8 @@ def test_conv_transpose_as_pixel_shuffle():
     assert_close(ops.conv2d(x.cuda(), pc, bias=b.cuda()), ref, 2e-6)
 
 
-@pytest.mark.parametrize("cfg", [(1, 6, 9, 11, 4), (2, 8, 16, 40, 32), (1, 12, 8, 32, 32), (1, 5, 3, 3, 3)])
+@pytest.mark.parametrize("cfg", [(1, 6, 9, 11, 4), (2, 8, 16, 40, 32), (1, 12, 8, 32, 32), (1, 5, 3, 3, 3), (1, 7, 20, 70, 32),
+                                 (1, 6, 9, 33, 40)])
 def test_conv3d_1k1_vs_torch_cpu(cfg):
     from cwfa_amd import ops
     B, D, H, W, K = cfg

@@ -11,38 +11,26 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
-VARIANTS = {
-    "base": [],
-    "minw4": ["-DCWFA_MINW=4"],
-    "wn4": ["-DCWFA_WN64=4", "-DCWFA_WN128=2", "-DCWFA_MINW=2"],
-    "wn4_nopf": ["-DCWFA_WN64=4", "-DCWFA_WN128=2", "-DCWFA_PREFETCH=0", "-DCWFA_MINW=3"],
-    "nopf_minw4": ["-DCWFA_PREFETCH=0", "-DCWFA_MINW=4"],
-    "ck16": ["-DCWFA_CK3=16"],
-    "wm1wn4_128": ["-DCWFA_WM128=1", "-DCWFA_WN128=4", "-DCWFA_WN64=4", "-DCWFA_MINW=2"],
+VARIANTS = {     # name -> (source the -D flags apply to, flags)
+    "base": ("conv_wino.hip", []),
+    "nostage": ("conv_wino.hip", ["-DCWFA_EXP_NOSTAGE"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
     (64, 64, 512, 512, 3), (256, 256, 512, 512, 3), (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
-    (64, 96, 512, 512, 3), (64, 64, 512, 512, 1), (29, 48, 512, 512, 3)]
+    (64, 96, 512, 512, 3)]
 
 
 def build():
     from cwfa_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
-    for name, defs in VARIANTS.items():
+    for name, (vsrc, defs) in VARIANTS.items():
         objs = []
         for s in b.SOURCES:
-            o = os.path.join(VDIR, f"{name}_{s[:-4]}.o")
-            extra = defs if s == "conv2d.hip" else []
-            if s != "conv2d.hip" and os.path.exists(os.path.join(VDIR, f"base_{s[:-4]}.o")):
-                o = os.path.join(VDIR, f"base_{s[:-4]}.o")
-            else:
-                r = subprocess.run([b.HIPCC, *b.FLAGS, *extra, "-c", os.path.join(b.CSRC, s), "-o", o,
-                                    "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+            o = os.path.join(VDIR, f"{name}_{s[:-4]}.o") if s == vsrc else os.path.join(VDIR, f"common_{s[:-4]}.o")
+            if s == vsrc or not os.path.exists(o) or os.path.getmtime(o) < os.path.getmtime(os.path.join(b.CSRC, s)):
+                r = subprocess.run([b.HIPCC, *b.FLAGS, *(defs if s == vsrc else []), "-c", os.path.join(b.CSRC, s), "-o", o],
+                                   capture_output=True, text=True)
                 assert r.returncode == 0, r.stderr[-3000:]
-                if s == "conv2d.hip":
-                    import re
-                    regs = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, flags=re.S)
-                    print(name, [(n[-40:-17], v, occ) for n, v, occ in regs if "conv2d" in n][:3])
             objs.append(o)
         subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VDIR, f"lib_{name}.so"),
                         *objs], check=True)
