@@ -22,6 +22,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CWFA_WDEPTH
+#define CWFA_WDEPTH 2
+#endif
+
 namespace {
 
 template <int K>
@@ -65,7 +69,10 @@ struct WParams {
 };
 
 #ifdef CWFA_EXP_STAMP
-__device__ long long g_stamps[8 * 40 * 5];
+__device__ long long g_stamps[8 * 40 * 10 + 64];
+#define LSTAMP(k) do { if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_stamps[8 * 40 * 10 + (threadIdx.x >> 6) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LSTAMP(k)
 #endif
 
 struct WTile {
@@ -221,24 +228,40 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     // k-steps of chunk c, and after every few steps ONE staging item: store item k of chunk c+1 to the other LDS buffer
     // (its loads were issued one chunk ago), then issue its loads for chunk c+2 into the registers just freed.
     // The LDS operands of k-step s+DEPTH are read while the MFMAs of step s issue; every step is fenced for the scheduler.
-    constexpr int NSTEP = 12 * (C::CK / 2), DEPTH = 2, SLOT0 = 1, SLOTD = (NSTEP - 2) / NITEM;
+    // The operand pipeline runs ACROSS the chunk barrier: the barrier sits DEPTH k-steps before the end of a chunk (every
+    // store of chunk c+1 is scheduled before it, and a wave's last reads of the current buffer are issued before it), the
+    // first reads of chunk c+1 follow it immediately, and the remaining MFMAs of chunk c cover their latency -- with the
+    // barrier at the very end both waves of a SIMD sat idle for one LDS round trip per chunk.
+    constexpr int NSTEP = 12 * (C::CK / 2), DEPTH = CWFA_WDEPTH, SLOT0 = 1, SLOTD = (NSTEP - DEPTH - 2) / NITEM;
+    static_assert(NSTEP % (DEPTH + 1) == 0 && SLOT0 + (NITEM - 1) * SLOTD < NSTEP - DEPTH, "slot ring / staging before the barrier");
+    float bq[DEPTH + 1], aq[DEPTH + 1][C::MT];
+    auto ld = [&](int buf, int s, int slot) {
+        const int kk = s % (C::CK / 2), xi = (s / (C::CK / 2)) % 4, ky = s / (4 * (C::CK / 2));
+        bq[slot] = (vlane0 + buf * C::BUF)[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
+        const f32x2 a2 = *reinterpret_cast<const f32x2*>(ulane0 + buf * C::BUF + ((ky * 4 + xi) * C::CK + 2 * kk) * C::CT);
+        aq[slot][0] = a2[0];
+        aq[slot][1] = a2[1];
+    };
+#ifdef CWFA_EXP_STAMP
+    const bool stamp_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0;
+#define STAMP(k) do { if (stamp_on && chunk < 40) g_stamps[((threadIdx.x >> 6) * 40 + chunk) * 10 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k)
+#endif
     auto mfmas = [&](int cur, int chunk, bool more, bool pf) {
-        const float* ulane = ulane0 + cur * C::BUF;
-        const float* vlane = vlane0 + cur * C::BUF;
-        float bq[DEPTH + 1], aq[DEPTH + 1][C::MT];
-        auto ld = [&](int s, int slot) {
-            const int kk = s % (C::CK / 2), xi = (s / (C::CK / 2)) % 4, ky = s / (4 * (C::CK / 2));
-            bq[slot] = vlane[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
-            const f32x2 a2 = *reinterpret_cast<const f32x2*>(ulane + ((ky * 4 + xi) * C::CK + 2 * kk) * C::CT);
-            aq[slot][0] = a2[0];
-            aq[slot][1] = a2[1];
-        };
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) ld(s, s);
         // compile-time step index: the staging item (and its register arrays) must resolve statically, whatever the unroller thinks
         static_for<NSTEP>([&](auto sc) {
             constexpr int s = decltype(sc)::value, xi = (s / (C::CK / 2)) % 4;
-            if constexpr (s + DEPTH < NSTEP) ld(s + DEPTH, (s + DEPTH) % (DEPTH + 1));
+            if constexpr (s % 6 == 0) STAMP(s / 6);
+            if constexpr (s + DEPTH == NSTEP) {
+                if (more) __syncthreads();
+                STAMP(8);
+            }
+            if constexpr (s + DEPTH < NSTEP) {
+                ld(cur, s + DEPTH, (s + DEPTH) % (DEPTH + 1));
+            } else {
+                if (more) ld(cur ^ 1, s + DEPTH - NSTEP, (s + DEPTH) % (DEPTH + 1));
+            }
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
                 acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % (DEPTH + 1)][m], bq[s % (DEPTH + 1)], acc[m][xi], 0, 0, 0);
@@ -252,27 +275,18 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-#ifdef CWFA_EXP_STAMP
-    const bool stamp_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0;
-#define STAMP(k) do { if (stamp_on && chunk < 40) g_stamps[((threadIdx.x >> 6) * 40 + chunk) * 5 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(k)
-#endif
     static_for<NITEM>([&](auto kc) { load_item(kc, 0); });
     static_for<NITEM>([&](auto kc) {
         store_item(kc, 0);
         if (1 < p.nchunks) load_item(kc, 1);
     });
     __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) ld(0, s, s);
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int cur = chunk & 1;
-        STAMP(0);
-        STAMP(1);
         mfmas(cur, chunk, chunk + 1 < p.nchunks, chunk + 2 < p.nchunks);
-        STAMP(2);
-        STAMP(3);
-        __syncthreads();
-        STAMP(4);
+        STAMP(9);
     }
 }
 
@@ -440,7 +454,9 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
     float* Us = smem + C::VS;
     const WTile t = make_wtile<C>(p);
     f32x16 acc[2][4];
+    LSTAMP(0);
     wino_mainloop<C, false>(p, t, smem, Us, acc);
+    LSTAMP(1);
 
     const int64_t HW = (int64_t)p.H * p.W;
     const int row = t.row0 + t.wn, col = t.col0 + 2 * t.l31;
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
     }
     __syncthreads();
     const float* wl = Us + (threadIdx.x & 63);
+    LSTAMP(2);
 
     auto load_res = [&](int mo, f32x2 (&res)[16]) {           // residual x + 1x1 bias of 16 output channels, both pixels
 #pragma unroll
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
         f32x2 o = {cwfa_elu(yq[2][rr] + rq1[rr][0]), cwfa_elu(yq[3][rr] + rq1[rr][1])};
         if (ok0) st2(yb, K * HW4 + oo, o, vec, ok0, ok1);
     }
+    LSTAMP(3);
 }
 
 struct WSel {

@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
     "base": ("conv_wino.hip", []),
-    "nostage": ("conv_wino.hip", ["-DCWFA_EXP_NOSTAGE"]),
+    "d3": ("conv_wino.hip", ["-DCWFA_WDEPTH=3"]),
+    "d5": ("conv_wino.hip", ["-DCWFA_WDEPTH=5"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
     (64, 64, 512, 512, 3), (256, 256, 512, 512, 3), (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),

@@ -26,12 +26,25 @@ else:
         ops.conv2d(x, pc, act="prelu", prelu_alpha=alpha)
     torch.cuda.synchronize()
     h = C.CDLL(_lib.LIB_PATH)
-    buf = (C.c_longlong * (8 * 40 * 5))()
-    assert h.cwfa_debug_stamps(buf, 8 * 40 * 5) == 0
-    t = np.array(buf, dtype=np.int64).reshape(8, 40, 5)[:, :32]
-    t0 = t[:, 4:28]                       # steady-state chunks
-    names = ["stage-before (early commit + prefetch)", "mfmas", "stage-after (late commit)", "barrier wait"]
+    N = 8 * 40 * 10
+    buf = (C.c_longlong * (N + 64))()
+    assert h.cwfa_debug_stamps(buf, N + 64) == 0
+    t = np.array(buf, dtype=np.int64)[:N].reshape(8, 40, 10)[:, 4:28]     # steady-state chunks
+    # stamps 0..7: k-steps 0,6,..,42; 8: after the barrier (before step 46); 9: end of chunk
     for w in range(8):
-        d = np.diff(t0[w], axis=1).mean(axis=0)
-        loop = np.diff(t0[w, :, 0]).mean()
-        print(f"wave {w}: " + "  ".join(f"{n.split()[0]} {v:7.0f}" for n, v in zip(names, d)) + f"   chunk {loop:7.0f} ticks")
+        seg = np.concatenate([np.diff(t[w][:, :8], axis=1), (t[w][:, 8] - t[w][:, 7])[:, None], (t[w][:, 9] - t[w][:, 8])[:, None]], axis=1).mean(axis=0)
+        print(f"wave {w}: " + " ".join(f"{v:6.0f}" for v in seg) + f"   chunk {np.diff(t[w][:, 0]).mean():7.0f}")
+    print("        (6 k-steps each: s0-5 s6-11 ... s36-41 | s42-45+barrier | s46-47)")
+    x = torch.randn(1, 64, 512, 512, device="cuda")
+    pc3 = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    pn = ops.pack_1x1_panel(torch.randn(64, 64, 1, 1, device="cuda") * 0.1)
+    b = torch.zeros(64, device="cuda")
+    for _ in range(3):
+        ops.subnet_layer(x, pc3, b, pn, b)
+    torch.cuda.synchronize()
+    assert h.cwfa_debug_stamps(buf, N + 64) == 0
+    l = np.array(buf, dtype=np.int64)[N:].reshape(8, 8)[:, :4]
+    c = np.array(buf, dtype=np.int64)[:N].reshape(8, 40, 10)[:, :8]
+    for w in (0, 4):
+        d = np.diff(l[w])
+        print(f"layer wave {w}: mainloop {d[0]} (prologue {c[w,0,0]-l[w,0]}, chunks {np.diff(c[w,:,0])})  panel {d[1]}  1x1+store {d[2]}  total {l[w,3]-l[w,0]}")
