@@ -29,30 +29,62 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chi
 PEAK_HBM_GBS = 8000.0
 
 
+def family(key):
+    """The kernel instantiation a conv launch runs (mirrors the dispatch in csrc/conv2d.hip / conv_wino.hip), i.e. ONE
+    kernel name in a rocprofv3 trace: launches of one family differ only in Cin / H / W / B."""
+    ks, cin, cout, H, W, B, tag = key[:7]
+    if ks == "L":
+        return "wino_layer_kernel"
+    if ks == 3 and cout >= 33:
+        return "conv3x3_wino_kernel<%s>[%s]" % ("W64" if cout <= 64 else "W128", tag)
+    return "conv2d_mfma_kernel<k%d,%s>[%s]" % (ks, "co<=32" if cout <= 32 else "co<=64" if cout <= 64 else "co>64", tag)
+
+
+# family -> substring of the kernel's name in a rocprofv3 trace (template arguments: config, epilogue id, prologue flag)
+ROCPROF_NAMES = {
+    "wino_layer_kernel": "wino_layer_kernel",
+    "conv3x3_wino_kernel<W128>[pro|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, true>",
+    "conv3x3_wino_kernel<W128>[|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, false>",
+    "conv3x3_wino_kernel<W128>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 2, false>",
+    "conv3x3_wino_kernel<W64>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 1, 8>, 2, false>",
+}
+
+
 class ConvEvents:
-    """Event sink for ops.conv2d: everything (selection pass) or one kernel/shape key (timed region)."""
+    """Event sink for ops.conv2d: everything (selection pass) or the launches of one kernel family (timed region)."""
 
     def __init__(self, only=None):
         self.only, self.rows = only, []
 
     def want(self, key):
-        return self.only is None or key == self.only
+        return self.only is None or family(key) == self.only
 
     def add(self, key, e0, e1):
         self.rows.append((key, e0, e1))
 
     def totals(self):
+        """family -> [ms, launches, flops, {shape: launches}]"""
         tot = {}
         for key, e0, e1 in self.rows:
-            t, n = tot.get(key, (0.0, 0))
-            tot[key] = (t + e0.elapsed_time(e1), n + 1)
+            t = tot.setdefault(family(key), [0.0, 0, 0.0, {}])
+            t[0] += e0.elapsed_time(e1)
+            t[1] += 1
+            t[2] += conv_flops(key)
+            t[3][key] = t[3].get(key, 0) + 1
         return tot
 
 
 def conv_flops(key):
-    ks, cin, cout, H, W, B = key
+    ks, cin, cout, H, W, B = key[:6]
     taps = 10 if ks == "L" else ks * ks          # "L": fused 3x3 + 1x1 sub-network layer (9 + 1 taps)
     return 2.0 * cout * cin * taps * H * W * B
+
+
+def conv_bytes(key):
+    """Algorithmic HBM bytes of one launch: every input tensor (x, and the skip tensor of a load-side add) read once, the
+    output written once; the fused layer's residual is the x tile it already holds.  Weights are L2-resident noise."""
+    ks, cin, cout, H, W, B = key[:6]
+    return 4.0 * (cin * (2 if key[7] else 1) + cout) * H * W * B
 
 
 def main():
@@ -107,8 +139,8 @@ def main():
     step()
     torch.cuda.synchronize()
     tot = sel.totals()
-    all_conv_ms = sum(t for t, _ in tot.values())
-    dom = max(tot, key=lambda k: tot[k][0])
+    all_conv_ms = sum(t[0] for t in tot.values())
+    dom = max(tot, key=lambda k: tot[k][0])                  # the kernel (one instantiation) with the largest time share
     ops.conv_event_sink = None
     for _ in range(max(a.warmup - 2, 0)):
         step()
@@ -128,9 +160,10 @@ def main():
 
     res = None
     if rank == 0:
-        t_dom, n_dom = sink.totals()[dom]
+        t_dom, n_dom, f_dom, shapes = sink.totals()[dom]
         avg_ms = t_dom / n_dom
-        tf = conv_flops(dom) / (avg_ms * 1e-3) / 1e12
+        tf = f_dom / (t_dom * 1e-3) / 1e12
+        alg_bytes = sum(conv_bytes(k) * n for k, n in shapes.items()) / n_dom
         res = {
             "metric": "volumes/sec inverse-pass @512x512x96 fp32", "value": world * a.steps * B / elapsed,
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -140,18 +173,23 @@ def main():
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
                                    f"batch {B}/GPU, random-init weights (BASELINE.json configs[2])",
                        "parallelism": f"replicated x{world} (independent volumes per GPU, no collective)"},
+            # achieved = algorithmic conv FLOPs (2*Cout*Cin*taps*H*W per launch) of ALL launches of
+            # the dominant kernel inside the timed region / their summed HIP-event durations; avg_launch_ms is the figure
+            # to compare with the rocprofv3 kernel-stats average for the same kernel (profiles/).
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": ("subnet_layer_kernel" if dom[0] == "L" else "conv2d_mfma_kernel") +
-                                   " (v_mfma_f32_32x32x2_f32)",
-                         "shape": dict(zip(("ks", "cin", "cout", "H", "W", "B"), dom)),
-                         "flops_per_launch": conv_flops(dom), "avg_launch_ms": avg_ms, "launches_timed": n_dom,
-                         "share_of_conv_time": tot[dom][0] / all_conv_ms,
-                         "all_conv_ms_per_step": all_conv_ms},
+                         "kernel": dom + " (v_mfma_f32_32x32x2_f32" + (", Winograd F(2,3): 1.5x fewer MFMAs than the "
+                                   "algorithmic count" if "wino" in dom else "") + ")",
+                         "mfma_issued_frac": tf / (1.5 if "wino" in dom else 1.0) / PEAK_FP32_MFMA_TFLOPS,
+                         "shapes": [dict(zip(("ks", "cin", "cout", "H", "W", "B", "launches"), (*k[:6], n)))
+                                    for k, n in sorted(shapes.items(), key=lambda kv: -kv[1])],
+                         "flops_per_launch": f_dom / n_dom, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": avg_ms, "launches_timed": n_dom,
+                         "share_of_conv_time": tot[dom][0] / all_conv_ms, "all_conv_ms_per_step": all_conv_ms},
             "reference_readme": {"volumes_per_s": 6.25, "note": "README.md:29, unstated CUDA GPU, fp16 autocast; not "
                                  "this fp32 metric, hence vs_baseline is null"},
         }
-        res["roofline"]["traffic"] = pmc_traffic(res["roofline"]["kernel"], dom)
+        res["roofline"]["traffic"], res["roofline"]["traffic_detail"] = pmc_traffic(dom, a)
         res["roofline_dwt"] = dwt_roofline(ops, a, dev)
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
             res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
@@ -162,21 +200,20 @@ def main():
     return res
 
 
-def pmc_traffic(kernel, dom):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-    cannot be collected from inside this process; profiles/*_pmc_traffic.json holds the latest separate-pass numbers,
-    taken on the same shape).  None if no matching record."""
+def pmc_traffic(dom, a):
+    """HBM bytes per launch of the dominant kernel.  FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process
+    (rocprofv3 --pmc, separate passes); profiles/*_pmc_traffic.json holds the latest such passes over THIS command, averaged
+    over the same launches as `achieved`, with the calibration described in DESIGN.md section 6.  (None, None) if the
+    committed record does not cover this kernel / workload."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files or dom[3:5] != (512, 512):
-        return None
-    rec = json.load(open(files[-1]))["kernels"]
-    name = kernel.split(" ")[0]
-    for k, v in rec.items():
-        if k.startswith(name) and (name != "conv2d_mfma_kernel" or "true" in k):
-            return {"bytes": (v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0, "source": os.path.basename(files[-1]),
-                    "algorithmic_bytes": 2 * 4.0 * dom[1] * dom[3] * dom[4] * dom[5]}
-    return None
+    if not files or (a.side, a.depths, a.batch) != (512, 96, 1):
+        return None, None
+    rec = json.load(open(files[-1]))
+    hit = rec.get("kernels", {}).get(dom)
+    if not hit:
+        return None, None
+    return hit["hbm_bytes_per_launch"], {"source": os.path.basename(files[-1]), **hit}
 
 
 def dwt_roofline(ops, a, dev, reps=20):

@@ -87,8 +87,22 @@ __device__ __forceinline__ WTile make_wtile(const WParams& p) {
     t.wn = wave % C::WN;
     t.kh = lane >> 5;
     t.l31 = lane & 31;
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-    t.ct = blockIdx.y;
+    // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so
+    // block id = 8*slot + xcd: XCD x works through its own contiguous band of spatial tiles (row-major: the halo rows and
+    // the column neighbours of a tile are read by the same L2), and the cout tiles of one spatial tile sit in consecutive
+    // slots of that XCD, so their re-reads of the same input hit L2 instead of the fabric.
+    const int ntiles = p.tiles_x * p.tiles_y, nct = (int)(gridDim.x / ntiles);
+    int tile, ct;
+    if ((ntiles & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        ct = slot % nct;
+        tile = xcd * (ntiles >> 3) + slot / nct;
+    } else {
+        ct = blockIdx.x % nct;
+        tile = blockIdx.x / nct;
+    }
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    t.ct = ct;
     t.b = blockIdx.z;
     t.row0 = ty * C::TR;
     t.col0 = tx * C::TCOLS;
@@ -546,7 +560,7 @@ int wlaunch(WParams p, hipStream_t stream) {
     p.tiles_y = (p.H + C::TR - 1) / C::TR;
     p.nchunks = (p.Cin + C::CK - 1) / C::CK;
     const int ctiles = (p.Cout + C::CT - 1) / C::CT;
-    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
+    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y * ctiles < (1ll << 31) && p.B <= 65535, CWFA_E_SHAPE,
                  "cwfa_conv2d_f32: grid too large");
     CWFA_REQUIRE((int64_t)(p.Cin + C::CK) * p.H * p.W * 4 < (1ll << 31), CWFA_E_SHAPE,
                  "cwfa_conv2d_f32: one sample's input must stay below 2 GiB (32-bit buffer offsets)");
@@ -561,7 +575,7 @@ int wlaunch(WParams p, hipStream_t stream) {
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * ctiles), 1, p.B);
     hipLaunchKernelGGL((conv3x3_wino_kernel<C, EPI, PRO>), grid, dim3(C::NTHREADS), LDS, stream, p);
     CWFA_LAUNCH_CHECK("cwfa_conv2d_f32 (winograd)");
     return CWFA_OK;

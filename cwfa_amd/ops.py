@@ -295,7 +295,10 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
     o.upshuffle2 = int(up)
     rec = conv_event_sink
     if rec is not None:                    # bench.py: HIP events around selected launches, on the launch stream
-        key = (pc.ks, Cin, pc.cout, H, W, B)
+        # the last field names the kernel instantiation the C side dispatches to (prologue / epilogue variant)
+        key = (pc.ks, Cin, pc.cout, H, W, B, "%s|%s|%s|%s|%s" % ("pro" if (in_scale is not None or in_add is not None) else "",
+                                                                 act or "", "res" if residual is not None else "", act2 or "",
+                                                                 "up" if up else ""), in_add is not None)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -331,7 +334,7 @@ def subnet_layer(x, pc3, b3, panel1, b1):
     out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
     rec = conv_event_sink
     if rec is not None:
-        key = ("L", 64, 64, H, W, B)
+        key = ("L", 64, 64, H, W, B, "layer", False)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
