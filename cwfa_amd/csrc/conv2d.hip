@@ -19,6 +19,8 @@
 #include "conv_internal.h"
 
 #include <string.h>
+#include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,9 +47,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int KS_, int CK_, int MT_, int NT_, int WM_, int WN_>
+template <int KS_, int CK_, int MT_, int NT_, int WM_, int WN_, int XV_ = 1>
 struct Cfg {
     static constexpr int KS = KS_, CK = CK_, MT = MT_, NT = NT_, WM = WM_, WN = WN_;
+    static constexpr int XV = XV_;                   // floats per staged input element (4: 1x1 convs on 16-byte aligned rows)
+    static_assert(XV_ == 1 || (XV_ == 4 && KS_ == 1), "vector staging needs halo-free tiles");
     static constexpr int PAD = KS / 2;
     static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int CT = 32 * MT * WM;          // output channels per block
@@ -58,9 +62,10 @@ struct Cfg {
     static constexpr int XS = CK * XR * XC;          // floats of the input tile
     static constexpr int XS_PAD = (XS + 3) & ~3;
     static constexpr int WS = KS * KS * CK * CT;     // floats of the weight panel (multiple of 4)
-    static constexpr int XPT = (XS + NTHREADS - 1) / NTHREADS;
+    static constexpr int XPT = (XS / XV + NTHREADS - 1) / NTHREADS;
     static constexpr int WPT = (WS / 4 + NTHREADS - 1) / NTHREADS;
-    static constexpr int LDS_BYTES = (XS_PAD + WS) * 4;
+    static constexpr int BUF = XS_PAD + WS;          // floats per LDS buffer (two buffers, see conv_mainloop)
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
 };
 
 struct ConvParams {
@@ -98,88 +103,124 @@ __device__ __forceinline__ Tile make_tile(const ConvParams& p) {
 // ------------------------------------------------------------------------------------------------ main loop
 // PRO = the load-side prologue (per-channel affine and/or added tensor) is compiled in; kernels without it do not pay
 // its staging registers.
+//
+// Schedule (same reasoning as conv_wino.hip, measured there): the fp32 MFMA and the vector ALU of a SIMD do not
+// co-execute, and a wave with an MFMA ready starves the vector instructions of the other waves on its SIMD, so staging
+// cannot be hidden behind "another wave's" MFMAs.  Every wave runs ONE stream: the k-steps of chunk c, and between them
+// the staging ITEMS of the block's next tiles -- store item k of chunk c+1 into the other LDS buffer (its loads were
+// issued a chunk ago), then issue its loads for chunk c+2 into the registers just freed.  Two LDS buffers, one barrier
+// per chunk, placed DEPTH k-steps before the end of the chunk so that the first operand reads of chunk c+1 are covered
+// by the last MFMAs of chunk c.  Global reads go through buffer descriptors: the per-lane byte offset is computed once,
+// the per-chunk part is the scalar soffset, and padding (outside the image, channels >= Cin) is an out-of-range offset
+// that the hardware range check returns as 0.0.
+template <int K>
+using sc_int = std::integral_constant<int, K>;
+template <class F, int... S>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, S...>) {
+    (f(sc_int<S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <class C, bool PRO>
-__device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t, float* Xs, float* Ws,
-                                              f32x16 (&acc)[C::MT][C::NT]) {
+__device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t, float* smem, f32x16 (&acc)[C::MT][C::NT]) {
     const int tid = threadIdx.x;
     const int64_t HW = (int64_t)p.H * p.W;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NP = PRO ? C::XPT : 1;
 
-    // per-thread staging map for the input tile (identical for every chunk); local channel -1 = padding / unused
-    int xoff[C::XPT];
-    int xcl[C::XPT];
+    // per-thread staging map for the input tile (identical for every chunk); an element is XV consecutive pixels
+    typedef float xvec __attribute__((ext_vector_type(C::XV == 1 ? 2 : C::XV)));      // (XV == 1 uses lane 0 only)
+    unsigned voff[C::XPT], cl4[NP];
+    unsigned long long okm[NP];                       // lane masks: element is inside the image (load-side affine only)
 #pragma unroll
     for (int i = 0; i < C::XPT; ++i) {
-        const int e = tid + i * C::NTHREADS;
+        const int e = (tid + i * C::NTHREADS) * C::XV;
         const int c = e / (C::XR * C::XC), rem = e % (C::XR * C::XC);
         const int r = rem / C::XC, cc = rem % C::XC;
         const int gr = t.row0 + r - C::PAD, gc = t.col0 + cc - C::PAD;
-        const bool ok = e < C::XS && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-        xcl[i] = ok ? c : -1;
-        xoff[i] = ok ? (int)(c * HW + (int64_t)gr * p.W + gc) : 0;
+        const bool ok = e < C::XS && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;       // XV == 4: W % 4 == 0 (dispatch)
+        voff[i] = ok ? (unsigned)((c * HW + (int64_t)gr * p.W + gc) * 4) : OOB;
+        if constexpr (PRO) {
+            cl4[i] = ok ? c * 4 : OOB;
+            okm[i] = __builtin_amdgcn_ballot_w64(ok);
+        }
     }
-    const float* xb = p.x + (int64_t)t.b * p.x_bs;
-    const float* ab = p.o.in_add ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : nullptr;
-    const float* wb = p.wp + (int64_t)t.ct * p.nchunks * C::WS;
+    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && p.o.in_add != nullptr;
+    const int xbytes = (int)((int64_t)p.Cin * HW * 4);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, xbytes, 0x00020000);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_add ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : p.x), 0, has_add ? xbytes : 0, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : p.x), 0, has_aff ? p.Cin * 4 : 0, 0x00020000);
+    const auto rsh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : p.x), 0, has_aff ? p.Cin * 4 : 0, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp + (int64_t)t.ct * p.nchunks * C::WS), 0,
+                                                      p.nchunks * C::WS * 4, 0x00020000);
+    const int chunk_bytes = (int)(C::CK * HW * 4);
+    auto ldf = [](decltype(rx) r, unsigned vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
+    auto ldx = [&](decltype(rx) r, unsigned vo, int so) {
+        xvec v;
+        if constexpr (C::XV == 4) v = __builtin_bit_cast(xvec, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+        else v[0] = ldf(r, vo, so);
+        return v;
+    };
 
-    // Staging registers.  Every global load below is UNCONDITIONAL (clamped address) and nothing waits on it here:
-    // per-element "load or zero" branches make hipcc wait vmcnt(0) element by element (measured +17 % on the UNet convs
-    // with the BatchNorm-on-load path); zeroing / the load-side affine / the skip add happen at commit time, one
-    // chunk later, when the data has long arrived.
-    constexpr int NP = PRO ? C::XPT : 1;
-    float xr[C::XPT], sr[NP], hr[NP], ar[NP];
+    xvec xr[C::XPT], ar[NP];
+    float sr[NP], hr[NP];
     f32x4 wr[C::WPT];
-    const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && ab != nullptr;
-    const float* scb = has_aff ? p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs : nullptr;
-    const float* shb = has_aff ? p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs : nullptr;
-
-    auto prefetch = [&](int chunk) {
-        const int c0 = chunk * C::CK;
-        const int64_t cbase = (int64_t)c0 * HW;
-        int off[C::XPT];
-#pragma unroll
-        for (int i = 0; i < C::XPT; ++i) off[i] = (xcl[i] >= 0 && c0 + xcl[i] < p.Cin) ? xoff[i] : 0;
-#pragma unroll
-        for (int i = 0; i < C::XPT; ++i) xr[i] = xb[cbase + off[i]];
+    auto load_x = [&](int i, int chunk) {
+        xr[i] = ldx(rx, voff[i], chunk * chunk_bytes);
         if constexpr (PRO) {
             if (has_aff) {
-#pragma unroll
-                for (int i = 0; i < C::XPT; ++i) {
-                    int ci = c0 + (xcl[i] < 0 ? 0 : xcl[i]);
-                    ci = ci < p.Cin ? ci : p.Cin - 1;
-                    sr[i] = scb[ci];
-                    hr[i] = shb[ci];
-                }
+                sr[i] = ldf(rsc, cl4[i], chunk * C::CK * 4);
+                hr[i] = ldf(rsh, cl4[i], chunk * C::CK * 4);
             }
-            if (has_add) {
-#pragma unroll
-                for (int i = 0; i < C::XPT; ++i) ar[i] = ab[cbase + off[i]];
-            }
-        }
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(wb + (int64_t)chunk * C::WS);
-#pragma unroll
-        for (int i = 0; i < C::WPT; ++i) {
-            const int e = tid + i * C::NTHREADS;
-            wr[i] = w4[e < C::WS / 4 ? e : 0];
+            if (has_add) ar[i] = ldx(ra, voff[i], chunk * chunk_bytes);
         }
     };
-    auto commit = [&](int chunk) {
-        const int c0 = chunk * C::CK;
+    auto store_x = [&](int i, int buf) {
+        xvec v = xr[i];
+        if constexpr (PRO) {
 #pragma unroll
-        for (int i = 0; i < C::XPT; ++i) {
-            const int e = tid + i * C::NTHREADS;
-            float v = xr[i];
-            if constexpr (PRO) {
-                if (has_aff) v = v * sr[i] + hr[i];
-                if (has_add) v += ar[i];
+            for (int j = 0; j < C::XV; ++j) {
+                float u = v[j];
+                if (has_aff) {
+                    u = u * sr[i] + hr[i];                              // zero padding is inserted AFTER the affine
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(u) : "v"(u), "s"(okm[i]));
+                }
+                if (has_add) u += ar[i][j];
+                v[j] = u;
             }
-            if (!(xcl[i] >= 0 && c0 + xcl[i] < p.Cin)) v = 0.f;          // zero padding is inserted AFTER the affine
-            if (e < C::XS) Xs[e] = v;
         }
-#pragma unroll
-        for (int i = 0; i < C::WPT; ++i) {
-            const int e = tid + i * C::NTHREADS;
-            if (e < C::WS / 4) reinterpret_cast<f32x4*>(Ws)[e] = wr[i];
+        const int e = (tid + i * C::NTHREADS) * C::XV;
+        if ((C::XS / C::XV) % C::NTHREADS == 0 || e < C::XS) {
+            if constexpr (C::XV == 4) *reinterpret_cast<xvec*>(smem + buf * C::BUF + e) = v;
+            else smem[buf * C::BUF + e] = v[0];
         }
+    };
+    // the weight panel of a chunk is WS/4 16-byte pieces; the last piece index of a thread may fall off the end (range check)
+    auto load_w = [&](int i, int chunk) {
+        wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rw, (unsigned)(tid + i * C::NTHREADS) < (unsigned)(C::WS / 4) ? (tid + i * C::NTHREADS) * 16u : OOB,
+                                              chunk * C::WS * 4, 0));
+    };
+    auto store_w = [&](int i, int buf) {
+        const int e = tid + i * C::NTHREADS;
+        if ((C::WS / 4) % C::NTHREADS == 0 || e < C::WS / 4) reinterpret_cast<f32x4*>(smem + buf * C::BUF + C::XS_PAD)[e] = wr[i];
+    };
+    constexpr int NITEM = C::XPT + C::WPT;
+    auto load_item = [&](auto kc, int chunk) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < C::XPT) load_x(k, chunk);
+        else load_w(k - C::XPT, chunk);
+    };
+    auto store_item = [&](auto kc, int buf) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < C::XPT) store_x(k, buf);
+        else store_w(k - C::XPT, buf);
     };
 
 #pragma unroll
@@ -189,39 +230,70 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const float* wlane = Ws + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
-    const float* xlane = Xs + t.kh * (C::XR * C::XC) + (t.wn * C::NT) * C::XC + t.l31;
+    const float* wlane0 = smem + C::XS_PAD + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
+    const float* xlane0 = smem + t.kh * (C::XR * C::XC) + (t.wn * C::NT) * C::XC + t.l31;
 
-#if CWFA_PREFETCH
-    prefetch(0);
-#endif
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        if (chunk) __syncthreads();
-#if !CWFA_PREFETCH
-        prefetch(chunk);
-#endif
-        commit(chunk);
-        __syncthreads();
-#if CWFA_PREFETCH
-        if (chunk + 1 < p.nchunks) prefetch(chunk + 1);
-#endif
+    constexpr int NSTEP = C::KS * C::KS * (C::CK / 2), DEPTH = 2, RING = DEPTH + 1;
+    constexpr int NSLOT = NSTEP - DEPTH;              // k-steps before the barrier: every item is stored in one of them
+    static_assert(NSTEP > DEPTH, "chunk shorter than the operand pipeline");
+    float aq[RING][C::MT], bq[RING][C::NT];
+    auto ld = [&](int buf, int s, int slot) {
+        const int tap = s / (C::CK / 2), kk = s % (C::CK / 2), dy = tap / C::KS, dx = tap % C::KS;
 #pragma unroll
-        for (int tap = 0; tap < C::KS * C::KS; ++tap) {
-            const int dy = tap / C::KS, dx = tap % C::KS;
+        for (int m = 0; m < C::MT; ++m) aq[slot][m] = (wlane0 + buf * C::BUF)[(tap * C::CK + 2 * kk) * C::CT + m * 32];
 #pragma unroll
-            for (int kk = 0; kk < C::CK / 2; ++kk) {
-                float a[C::MT], bv[C::NT];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m) a[m] = wlane[(tap * C::CK + 2 * kk) * C::CT + m * 32];
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n) bv[n] = xlane[(2 * kk) * (C::XR * C::XC) + (n + dy) * C::XC + dx];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < C::NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < C::NT; ++n) bq[slot][n] = (xlane0 + buf * C::BUF)[(2 * kk) * (C::XR * C::XC) + (n + dy) * C::XC + dx];
+    };
+    auto chunk_body = [&](int cur, int chunk, bool more, bool pf, auto ring0c) {
+        constexpr int ring0 = decltype(ring0c)::value;             // ring slot of k-step 0 (NSTEP need not divide by RING)
+        static_for<NSTEP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s == NSLOT) {
+                if (more) __syncthreads();
             }
-        }
+            if constexpr (s + DEPTH < NSTEP) {
+                ld(cur, s + DEPTH, (ring0 + s + DEPTH) % RING);
+            } else {
+                if (more) ld(cur ^ 1, s + DEPTH - NSTEP, (ring0 + s + DEPTH) % RING);
+            }
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(ring0 + s) % RING][m], bq[(ring0 + s) % RING][n], acc[m][n], 0, 0, 0);
+            if constexpr (s < NSLOT) {
+                // items [k0, k1) are staged after this step: NITEM items spread evenly over the NSLOT steps
+                constexpr int k0 = s * NITEM / NSLOT, k1 = (s + 1) * NITEM / NSLOT;
+                static_for<k1 - k0>([&](auto jc) {
+                    constexpr int k = k0 + decltype(jc)::value;
+                    if (more) store_item(sc_int<k>{}, cur ^ 1);
+                    if (pf) load_item(sc_int<k>{}, chunk + 2);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    static_for<NITEM>([&](auto kc) { load_item(kc, 0); });
+    static_for<NITEM>([&](auto kc) {
+        store_item(kc, 0);
+        if (1 < p.nchunks) load_item(kc, 1);
+    });
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) ld(0, s, s);
+    // the ring position of k-step 0 advances by NSTEP % RING per chunk: unroll the chunk loop over the RING phases
+    constexpr int ADV = NSTEP % RING;
+    int chunk = 0;
+    while (chunk < p.nchunks) {
+        static_for<RING>([&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            if (chunk < p.nchunks) {
+                chunk_body(chunk & 1, chunk, chunk + 1 < p.nchunks, chunk + 2 < p.nchunks, sc_int<(ph * ADV) % RING>{});
+                ++chunk;
+            }
+        });
+        if constexpr (ADV == 0) continue;
     }
 }
 
@@ -374,7 +446,7 @@ __global__ __launch_bounds__(C::NTHREADS, CWFA_MINW) void conv2d_mfma_kernel(Con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Tile t = make_tile<C>(p);
     f32x16 acc[C::MT][C::NT];
-    conv_mainloop<C, PRO>(p, t, smem, smem + C::XS_PAD, acc);
+    conv_mainloop<C, PRO>(p, t, smem, acc);
     epilogue<C, EPI>(p, t, acc);
 }
 
@@ -393,7 +465,7 @@ __global__ __launch_bounds__(CL::NTHREADS, 1) void subnet_layer_kernel(ConvParam
     float* Ws = smem + C::XS_PAD;
     const Tile t = make_tile<C>(p);
     f32x16 acc[2][2];
-    conv_mainloop<C, false>(p, t, smem, Ws, acc);
+    conv_mainloop<C, false>(p, t, smem, acc);
 
     const int64_t HW = (int64_t)p.H * p.W;
     const int col = t.col0 + t.l31;
@@ -518,6 +590,9 @@ typedef Cfg<3, CWFA_CK3, 2, 2, CWFA_WM128, CWFA_WN128> C3_128;     // Cout  > 64
 typedef Cfg<1, 16, 1, 4, 1, 4> C1_32;
 typedef Cfg<1, 16, 2, 2, 1, CWFA_WN64> C1_64;
 typedef Cfg<1, 16, 2, 2, CWFA_WM128, CWFA_WN128> C1_128;
+typedef Cfg<1, 16, 1, 4, 1, 4, 4> C1v_32;                           // the same tiles staged 16 bytes per lane
+typedef Cfg<1, 16, 2, 2, 1, CWFA_WN64, 4> C1v_64;
+typedef Cfg<1, 16, 2, 2, CWFA_WM128, CWFA_WN128, 4> C1v_128;
 typedef Cfg<7, 4, 1, 4, 1, 4> C7_32;
 typedef Cfg<7, 4, 2, 2, 1, 8> C7_64;
 
@@ -555,6 +630,8 @@ int prepare(ConvParams& p, dim3& grid) {
     const int ctiles = (p.Cout + C::CT - 1) / C::CT;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
                  "cwfa_conv2d_f32: grid too large");
+    CWFA_REQUIRE((int64_t)(p.Cin + C::CK) * p.H * p.W * 4 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv2d_f32: one sample's input must stay below 2 GiB (32-bit buffer offsets)");
     grid = dim3((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B);
     return CWFA_OK;
 }
@@ -674,6 +751,16 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
     if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_conv(x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, p.o, st);
     constexpr unsigned N = 1u << EPI_NONE, E = 1u << EPI_ELU, RE = 1u << EPI_RES_ELU, P = 1u << EPI_PRELU,
                        RP = 1u << EPI_RES_PRELU, G = 1u << EPI_GELU_RES, U = 1u << EPI_UP;
+    // 1x1: rows of 4-pixel groups on 16-byte boundaries (image, skip tensor, batch strides) take the vector-staged kernels
+    const bool v4 = ks == 1 && (W & 3) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (!p.o.in_add || ((p.o.in_add_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.o.in_add) & 15) == 0));
+    if (v4) {
+        switch (s.id) {
+            case 3: return launch<C1v_32, N | P | G, P>(p, epi, st);
+            case 4: return launch<C1v_64, N | RE | G, 0>(p, epi, st);
+            default: return launch<C1v_128, N | U, U>(p, epi, st);
+        }
+    }
     switch (s.id) {
         case 0: return launch<C3_32, N | P | RP, 0>(p, epi, st);
         case 1: return launch<C3_64, N | E | P | RP, 0>(p, epi, st);

@@ -111,6 +111,7 @@ def test_haar2d_then_haar1d_is_the_3d_tile():
     (1, 3, 5, 7, 2, 3), (2, 29, 20, 33, 6, 3), (1, 8, 16, 32, 64, 3), (1, 64, 33, 70, 64, 3), (2, 64, 16, 16, 96, 3),
     (1, 20, 17, 40, 130, 3), (1, 64, 18, 34, 64, 1), (2, 12, 9, 31, 8, 1), (1, 70, 16, 32, 200, 1),
     (1, 6, 23, 41, 6, 7), (1, 10, 16, 38, 40, 7), (1, 256, 16, 32, 128, 3),
+    (2, 40, 9, 36, 24, 1), (1, 64, 10, 64, 64, 1),          # 1x1 on 16-byte aligned rows: vector-staged kernels
 ])
 def test_conv2d_vs_torch_cpu(cfg):
     from cwfa_amd import ops
@@ -214,10 +215,11 @@ def test_conv2d_generic_epilogue_combo():
     assert_close(y, ref, 3e-6)
 
 
-def test_conv_transpose_as_pixel_shuffle():
+@pytest.mark.parametrize("wd", [13, 16])
+def test_conv_transpose_as_pixel_shuffle(wd):
     from cwfa_amd import ops
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 24, 9, 13, generator=g)
+    x = torch.randn(2, 24, 9, wd, generator=g)
     w = torch.randn(24, 10, 2, 2, generator=g) * 0.2
     b = torch.randn(10, generator=g)
     pc = ops.pack_conv_weight(w.cuda(), transposed=True)
