@@ -703,7 +703,7 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
 
 }  // namespace
 
-int g_cwfa_wino_min_cout = 33;
+int g_cwfa_wino_min_cout = 1;
 
 extern "C" int cwfa_set_option(const char* name, int value) {
     CWFA_REQUIRE(name, CWFA_E_INVAL, "cwfa_set_option: null name");

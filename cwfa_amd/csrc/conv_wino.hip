@@ -51,7 +51,9 @@ struct WCfg {
     static constexpr int VS = 4 * VPLANE;
     static constexpr int US = 12 * CK * CT;
     static constexpr int VPT = VPLANE / NTHREADS;    // (channel,row,tile) positions per thread
-    static constexpr int UPT = (US / 4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int UV = US % (4 * NTHREADS) == 0 ? 4 : 2;   // floats per staged piece of the U panel
+    static constexpr int UPT = US / UV / NTHREADS;
+    static_assert(US % (UV * NTHREADS) == 0, "U panel is a whole number of pieces per thread");
     static constexpr int BUF = VS + US;              // floats per LDS buffer (two buffers, see wino_mainloop)
     static constexpr int LDS_BYTES = 2 * BUF * 4;
     static_assert(VPLANE % NTHREADS == 0 && NTHREADS % 32 == 0, "staging map assumes whole tile rows per thread stride");
@@ -159,7 +161,7 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp + (int64_t)t.ct * p.nchunks * C::US), 0,
                                                       p.nchunks * C::US * 4, 0x00020000);
     const int chunk_bytes = (int)(C::CK * HW * 4);
-    const unsigned uoff = tid * 16;
+    const unsigned uoff = tid * 4 * C::UV;
     auto ldf = [](decltype(rx) r, unsigned vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
 
     constexpr int NP = PRO ? C::VPT : 1;
@@ -186,8 +188,14 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
         }
     };
     auto load_u = [&](int i, int chunk) {
-        static_assert(C::US / 4 == C::UPT * C::NTHREADS, "U panel is a whole number of 16-byte pieces per thread");
-        ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, uoff, (chunk * C::US + i * C::NTHREADS * 4) * 4, 0));
+        const int so = (chunk * C::US + i * C::NTHREADS * C::UV) * 4;
+        if constexpr (C::UV == 4) {
+            ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, uoff, so, 0));
+        } else {
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, uoff, so, 0));
+            ur[i][0] = v[0];
+            ur[i][1] = v[1];
+        }
     };
     auto store_v = [&](int i, int buf) {
         float d[4];
@@ -209,7 +217,14 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
         dst[2 * C::VPLANE] = d[2] - d[1];
         dst[3 * C::VPLANE] = d[1] - d[3];
     };
-    auto store_u = [&](int i, int buf) { reinterpret_cast<f32x4*>(Us + buf * C::BUF)[tid + i * C::NTHREADS] = ur[i]; };
+    auto store_u = [&](int i, int buf) {
+        if constexpr (C::UV == 4) {
+            reinterpret_cast<f32x4*>(Us + buf * C::BUF)[tid + i * C::NTHREADS] = ur[i];
+        } else {
+            const f32x2 v = {ur[i][0], ur[i][1]};
+            reinterpret_cast<f32x2*>(Us + buf * C::BUF)[tid + i * C::NTHREADS] = v;
+        }
+    };
     constexpr int NITEM = C::VPT + C::UPT;
     auto load_item = [&](auto kc, int chunk) {
         constexpr int k = decltype(kc)::value;
@@ -229,8 +244,8 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][xi][r] = 0.f;
 
-    static_assert(C::MT == 2, "U panel layout interleaves exactly two m-tiles");
-    const float* ulane0 = Us + t.kh * C::CT + t.wm * 64 + 2 * t.l31;
+    static_assert(C::MT == 1 || C::MT == 2, "U panel layout: one m-tile, or two interleaved");
+    const float* ulane0 = Us + t.kh * C::CT + t.wm * 32 * C::MT + C::MT * t.l31;
     const float* vlane0 = Vs + (t.kh * C::XR + t.wn) * 32 + t.l31;
 
     // Schedule.  Two LDS buffers, ONE barrier per chunk.  On gfx950 the fp32 MFMA and the vector ALU do not co-execute
@@ -252,9 +267,14 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     auto ld = [&](int buf, int s, int slot) {
         const int kk = s % (C::CK / 2), xi = (s / (C::CK / 2)) % 4, ky = s / (4 * (C::CK / 2));
         bq[slot] = (vlane0 + buf * C::BUF)[xi * C::VPLANE + ((2 * kk) * C::XR + ky) * 32];
-        const f32x2 a2 = *reinterpret_cast<const f32x2*>(ulane0 + buf * C::BUF + ((ky * 4 + xi) * C::CK + 2 * kk) * C::CT);
-        aq[slot][0] = a2[0];
-        aq[slot][1] = a2[1];
+        const float* ua = ulane0 + buf * C::BUF + ((ky * 4 + xi) * C::CK + 2 * kk) * C::CT;
+        if constexpr (C::MT == 2) {
+            const f32x2 a2 = *reinterpret_cast<const f32x2*>(ua);
+            aq[slot][0] = a2[0];
+            aq[slot][1] = a2[1];
+        } else {
+            aq[slot][0] = *ua;
+        }
     };
 #ifdef CWFA_EXP_STAMP
     const bool stamp_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0;
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     const int ctile = (int)(i / ((int64_t)CT * CK * 12 * nchunks));
     // within a panel the two 32-channel m-tiles of a wave are interleaved (position 64g + 2i + m <-> channel 64g + 32m + i)
     // so a lane fetches its A operands for both tiles with ONE ds_read_b64
-    const int co = ctile * CT + (col & ~63) + (col & 1) * 32 + ((col & 63) >> 1), ci = chunk * CK + ck;
+    const int co = ctile * CT + (CT >= 64 ? (col & ~63) + (col & 1) * 32 + ((col & 63) >> 1) : col), ci = chunk * CK + ck;
     float v = 0.f;
     if (co < Cout && ci < Cin) {
         const float* g = w + (((int64_t)co * Cin + ci) * 3 + ky) * 3;
@@ -428,6 +448,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     out[i] = v;
 }
 
+typedef WCfg<8, 1, 1, 8> W32;       // Cout <= 32: 32 ch x 8 rows x 64 cols, 512 threads (one m-tile per wave)
 typedef WCfg<8, 2, 1, 8> W64;       // Cout <= 64: 64 ch x 8 rows x 64 cols, 512 threads
 typedef WCfg<8, 2, 2, 4> W128;      // Cout  > 64: 128 ch x 4 rows x 64 cols, 512 threads
 
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
 struct WSel {
     int CT, CK;
 };
-WSel wsel(int Cout) { return Cout <= 64 ? WSel{W64::CT, W64::CK} : WSel{W128::CT, W128::CK}; }
+WSel wsel(int Cout) { return Cout <= 32 ? WSel{W32::CT, W32::CK} : Cout <= 64 ? WSel{W64::CT, W64::CK} : WSel{W128::CT, W128::CK}; }
 
 template <class C, int EPI, bool PRO>
 int wlaunch(WParams p, hipStream_t stream) {
@@ -619,6 +640,15 @@ int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int C
     p.o = o;
     const bool pro = o.in_scale || o.in_add;
     const int epi = classify(o);
+    if (Cout <= 32) {
+        if (pro) return wlaunch<W32, WEPI_GENERIC, true>(p, stream);
+        switch (epi) {
+            case WEPI_NONE: return wlaunch<W32, WEPI_NONE, false>(p, stream);
+            case WEPI_PRELU: return wlaunch<W32, WEPI_PRELU, false>(p, stream);
+            case WEPI_RES_PRELU: return wlaunch<W32, WEPI_RES_PRELU, false>(p, stream);
+            default: return wlaunch<W32, WEPI_GENERIC, false>(p, stream);
+        }
+    }
     if (Cout <= 64) {
         if (pro) return wlaunch<W64, WEPI_GENERIC, true>(p, stream);
         switch (epi) {

@@ -114,6 +114,16 @@ def test_haar2d_then_haar1d_is_the_3d_tile():
     (2, 40, 9, 36, 24, 1), (1, 64, 10, 64, 64, 1),          # 1x1 on 16-byte aligned rows: vector-staged kernels
 ])
 def test_conv2d_vs_torch_cpu(cfg):
+    """Direct implicit-GEMM kernels: 1x1 and 7x7 always, 3x3 with the Winograd path switched off (it is the default)."""
+    from cwfa_amd import ops
+    ops.set_option("winograd_min_cout", 1 << 20)
+    try:
+        _conv2d_case(cfg)
+    finally:
+        ops.set_option("winograd_min_cout", 1)
+
+
+def _conv2d_case(cfg):
     from cwfa_amd import ops
     B, Cin, H, W, Cout, ks = cfg
     g = torch.Generator().manual_seed(hash(cfg) % 1000)
@@ -148,13 +158,13 @@ def test_subnet_layer_fused_vs_torch_cpu(shape):
     F = torch.nn.functional
     xd = x.double()
     ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
-    for min_cout in (33, 1 << 20):           # Winograd fused kernel (default) and the direct fused kernel
+    for min_cout in (1, 1 << 20):            # Winograd fused kernel (default) and the direct fused kernel
         ops.set_option("winograd_min_cout", min_cout)
         try:
             y = ops.subnet_layer(x.cuda(), ops.pack_conv_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()),
                                  b1.cuda())
         finally:
-            ops.set_option("winograd_min_cout", 33)
+            ops.set_option("winograd_min_cout", 1)
         assert_close(y, ref, 3e-6, f"fused layer, winograd_min_cout={min_cout}")
     # the unfused two-launch form agrees too
     h = ops.conv2d(x.cuda(), ops.pack_conv_weight(w3.cuda()), bias=b3.cuda(), act="elu")
@@ -163,8 +173,9 @@ def test_subnet_layer_fused_vs_torch_cpu(shape):
 
 
 @pytest.mark.parametrize("cfg", [
-    # (B, Cin, H, W, Cout): 3x3 convs through the Winograd F(2,3) kernels (threshold lowered to 33 for the test)
+    # (B, Cin, H, W, Cout): 3x3 convs through the Winograd F(2,3) kernels (the default for every 3x3), all three tilings
     (1, 64, 16, 64, 64), (2, 29, 21, 37, 48), (1, 8, 9, 130, 40), (1, 70, 7, 63, 130), (1, 256, 8, 64, 128), (1, 6, 12, 66, 256),
+    (2, 29, 21, 37, 6), (1, 64, 16, 64, 24), (1, 5, 3, 3, 32),
 ])
 def test_conv3x3_winograd_vs_torch_cpu(cfg):
     from cwfa_amd import ops
@@ -181,7 +192,7 @@ def test_conv3x3_winograd_vs_torch_cpu(cfg):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
     ref_pro = F.prelu(F.conv2d(xin, w.double(), b.double(), padding=1), alpha.double())
-    ops.set_option("winograd_min_cout", 33)
+    ops.set_option("winograd_min_cout", 1)
     try:
         pc = ops.pack_conv_weight(w.cuda())
         got = {
@@ -194,7 +205,7 @@ def test_conv3x3_winograd_vs_torch_cpu(cfg):
                                     in_shift=sh.cuda(), in_add=add.cuda()),
         }
     finally:
-        ops.set_option("winograd_min_cout", 33)
+        ops.set_option("winograd_min_cout", 1)
     want = {"plain": ref, "elu": F.elu(ref), "prelu": F.prelu(ref, alpha.double()),
             "res_prelu": F.prelu(ref + res.double(), alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
             "pro_prelu": ref_pro}
