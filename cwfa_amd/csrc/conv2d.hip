@@ -233,7 +233,9 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
     const float* wlane0 = smem + C::XS_PAD + t.kh * C::CT + (t.wm * C::MT) * 32 + t.l31;
     const float* xlane0 = smem + t.kh * (C::XR * C::XC) + (t.wn * C::NT) * C::XC + t.l31;
 
-    constexpr int NSTEP = C::KS * C::KS * (C::CK / 2), DEPTH = 2, RING = DEPTH + 1;
+    // operand look-ahead in k-steps (each MT*NT MFMAs), chosen so that the register ring divides the chunk
+    constexpr int NSTEP = C::KS * C::KS * (C::CK / 2), DEPTH = C::KS == 1 ? 3 : C::KS == 3 ? 2 : 1, RING = DEPTH + 1;
+    static_assert(NSTEP % RING == 0, "operand ring must divide the k-steps of a chunk");
     constexpr int NSLOT = NSTEP - DEPTH;              // k-steps before the barrier: every item is stored in one of them
     static_assert(NSTEP > DEPTH, "chunk shorter than the operand pipeline");
     float aq[RING][C::MT], bq[RING][C::NT];
@@ -244,17 +246,18 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
 #pragma unroll
         for (int n = 0; n < C::NT; ++n) bq[slot][n] = (xlane0 + buf * C::BUF)[(2 * kk) * (C::XR * C::XC) + (n + dy) * C::XC + dx];
     };
-    auto chunk_body = [&](int cur, int chunk, bool more, bool pf, auto ring0c) {
-        constexpr int ring0 = decltype(ring0c)::value;             // ring slot of k-step 0 (NSTEP need not divide by RING)
+    // MORE / PF (is there a chunk c+1 to store, a chunk c+2 to load) are compile-time: the steady-state body carries no
+    // branches; the last two chunks run their own copies
+    auto chunk_body = [&](int cur, int chunk, auto morec, auto pfc) {
+        constexpr bool more = decltype(morec)::value, pf = decltype(pfc)::value;
+        constexpr int ring0 = 0;
         static_for<NSTEP>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if constexpr (s == NSLOT) {
-                if (more) __syncthreads();
-            }
+            if constexpr (s == NSLOT && more) __syncthreads();
             if constexpr (s + DEPTH < NSTEP) {
                 ld(cur, s + DEPTH, (ring0 + s + DEPTH) % RING);
-            } else {
-                if (more) ld(cur ^ 1, s + DEPTH - NSTEP, (ring0 + s + DEPTH) % RING);
+            } else if constexpr (more) {
+                ld(cur ^ 1, s + DEPTH - NSTEP, (ring0 + s + DEPTH) % RING);
             }
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
@@ -266,8 +269,8 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
                 constexpr int k0 = s * NITEM / NSLOT, k1 = (s + 1) * NITEM / NSLOT;
                 static_for<k1 - k0>([&](auto jc) {
                     constexpr int k = k0 + decltype(jc)::value;
-                    if (more) store_item(sc_int<k>{}, cur ^ 1);
-                    if (pf) load_item(sc_int<k>{}, chunk + 2);
+                    if constexpr (more) store_item(sc_int<k>{}, cur ^ 1);
+                    if constexpr (pf) load_item(sc_int<k>{}, chunk + 2);
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -282,19 +285,15 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) ld(0, s, s);
-    // the ring position of k-step 0 advances by NSTEP % RING per chunk: unroll the chunk loop over the RING phases
-    constexpr int ADV = NSTEP % RING;
+    typedef std::true_type T;
+    typedef std::false_type F;
     int chunk = 0;
-    while (chunk < p.nchunks) {
-        static_for<RING>([&](auto phc) {
-            constexpr int ph = decltype(phc)::value;
-            if (chunk < p.nchunks) {
-                chunk_body(chunk & 1, chunk, chunk + 1 < p.nchunks, chunk + 2 < p.nchunks, sc_int<(ph * ADV) % RING>{});
-                ++chunk;
-            }
-        });
-        if constexpr (ADV == 0) continue;
+    for (; chunk + 2 < p.nchunks; ++chunk) chunk_body(chunk & 1, chunk, T{}, T{});
+    if (chunk + 1 < p.nchunks) {
+        chunk_body(chunk & 1, chunk, T{}, F{});
+        ++chunk;
     }
+    chunk_body(chunk & 1, chunk, F{}, F{});
 }
 
 // scalar base + 32-bit unsigned BYTE offset: lowers to the saddr + voffset form (one VGPR per address instead of two)

@@ -282,19 +282,22 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #else
 #define STAMP(k)
 #endif
-    auto mfmas = [&](int cur, int chunk, bool more, bool pf) {
+    // MORE / PF (is there a chunk c+1 to store, a chunk c+2 to load) are compile-time: the steady-state body carries no
+    // branches, the last two chunks run their own copies
+    auto mfmas = [&](int cur, int chunk, auto morec, auto pfc) {
+        constexpr bool more = decltype(morec)::value, pf = decltype(pfc)::value;
         // compile-time step index: the staging item (and its register arrays) must resolve statically, whatever the unroller thinks
         static_for<NSTEP>([&](auto sc) {
             constexpr int s = decltype(sc)::value, xi = (s / (C::CK / 2)) % 4;
             if constexpr (s % 6 == 0) STAMP(s / 6);
             if constexpr (s + DEPTH == NSTEP) {
-                if (more) __syncthreads();
+                if constexpr (more) __syncthreads();
                 STAMP(8);
             }
             if constexpr (s + DEPTH < NSTEP) {
                 ld(cur, s + DEPTH, (s + DEPTH) % (DEPTH + 1));
-            } else {
-                if (more) ld(cur ^ 1, s + DEPTH - NSTEP, (s + DEPTH) % (DEPTH + 1));
+            } else if constexpr (more) {
+                ld(cur ^ 1, s + DEPTH - NSTEP, (s + DEPTH) % (DEPTH + 1));
             }
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
@@ -302,8 +305,8 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #ifndef CWFA_EXP_NOSTAGE
             if constexpr (s >= SLOT0 && (s - SLOT0) % SLOTD == 0 && (s - SLOT0) / SLOTD < NITEM) {
                 constexpr int k = (s - SLOT0) / SLOTD;
-                if (more) store_item(sc_int<k>{}, cur ^ 1);
-                if (pf) load_item(sc_int<k>{}, chunk + 2);
+                if constexpr (more) store_item(sc_int<k>{}, cur ^ 1);
+                if constexpr (pf) load_item(sc_int<k>{}, chunk + 2);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -317,11 +320,18 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) ld(0, s, s);
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int cur = chunk & 1;
-        mfmas(cur, chunk, chunk + 1 < p.nchunks, chunk + 2 < p.nchunks);
+    typedef std::true_type T;
+    typedef std::false_type F;
+    int chunk = 0;
+    for (; chunk + 2 < p.nchunks; ++chunk) {
+        mfmas(chunk & 1, chunk, T{}, T{});
         STAMP(9);
     }
+    if (chunk + 1 < p.nchunks) {
+        mfmas(chunk & 1, chunk, T{}, F{});
+        ++chunk;
+    }
+    mfmas(chunk & 1, chunk, F{}, F{});
 }
 
 // ------------------------------------------------------------------------------------------------ epilogues
