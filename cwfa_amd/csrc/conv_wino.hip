@@ -431,8 +431,11 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv3x3_wino_kernel(WParams p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WTile t = make_wtile<C>(p);
     f32x16 acc[C::MT][4];
+    LSTAMP(0);
     wino_mainloop<C, PRO>(p, t, smem, smem + C::VS, acc);
+    LSTAMP(1);
     wino_epilogue<C, EPI>(p, t, acc, smem);
+    LSTAMP(2);
 }
 
 // ---- weight transform + repack: torch [Cout][Cin][3][3] -> [cout tile][chunk][ky][xi][ck][CT]

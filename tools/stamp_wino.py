@@ -19,8 +19,9 @@ else:
     from cwfa_amd import _lib
     _lib.LIB_PATH = os.path.join(VDIR, "lib_stamp.so")
     from cwfa_amd import ops
-    x = torch.randn(1, 256, 512, 512, device="cuda")
-    pc = ops.pack_conv_weight(torch.randn(256, 256, 3, 3, device="cuda") * 0.05)
+    CH, HH = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 512)
+    x = torch.randn(1, CH, HH, HH, device="cuda")
+    pc = ops.pack_conv_weight(torch.randn(CH, CH, 3, 3, device="cuda") * 0.05)
     alpha = torch.tensor([0.25], device="cuda")
     for _ in range(3):
         ops.conv2d(x, pc, act="prelu", prelu_alpha=alpha)
@@ -34,6 +35,10 @@ else:
     for w in range(8):
         seg = np.concatenate([np.diff(t[w][:, :8], axis=1), (t[w][:, 8] - t[w][:, 7])[:, None], (t[w][:, 9] - t[w][:, 8])[:, None]], axis=1).mean(axis=0)
         print(f"wave {w}: " + " ".join(f"{v:6.0f}" for v in seg) + f"   chunk {np.diff(t[w][:, 0]).mean():7.0f}")
+    l = np.array(buf, dtype=np.int64)[N:].reshape(8, 8)[:, :3]
+    c = np.array(buf, dtype=np.int64)[:N].reshape(8, 40, 10)
+    for w in (0, 4):
+        print(f"block wave {w}: prologue {c[w,0,0]-l[w,0]}  mainloop {l[w,1]-l[w,0]}  epilogue {l[w,2]-l[w,1]}")
     print("        (6 k-steps each: s0-5 s6-11 ... s36-41 | s42-45+barrier | s46-47)")
     x = torch.randn(1, 64, 512, 512, device="cuda")
     pc3 = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
