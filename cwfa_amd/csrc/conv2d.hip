@@ -703,11 +703,16 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
 }  // namespace
 
 int g_cwfa_wino_min_cout = 1;
+int g_cwfa_wino_2d = 0;
 
 extern "C" int cwfa_set_option(const char* name, int value) {
     CWFA_REQUIRE(name, CWFA_E_INVAL, "cwfa_set_option: null name");
     if (strcmp(name, "winograd_min_cout") == 0) {
         g_cwfa_wino_min_cout = value;
+        return CWFA_OK;
+    }
+    if (strcmp(name, "winograd_2d") == 0) {
+        g_cwfa_wino_2d = value;
         return CWFA_OK;
     }
     cwfa_set_error("cwfa_set_option: unknown option '%s'", name);

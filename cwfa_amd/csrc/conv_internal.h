@@ -2,11 +2,19 @@
 #pragma once
 #include "common.h"
 
-// 3x3 convolutions with more than 32 output channels run the 1-D Winograd F(2,3) kernels: 1.5x fewer MFMAs.
-// The packed weight image differs (G-transformed along kx), so pack and launch must agree on this predicate.
-// The threshold is a run-time option ("winograd_min_cout", cwfa_set_option): 33 = default, a huge value = direct only.
+// 3x3 convolutions with at least g_cwfa_wino_min_cout output channels run the Winograd kernels (1.5x / 2.25x fewer MFMAs).
+// The packed weight image differs (G-transformed), so pack and launch must agree on these predicates.
+// The threshold is a run-time option ("winograd_min_cout", cwfa_set_option): 1 = default, a huge value = direct only.
 extern int g_cwfa_wino_min_cout;
 static inline bool cwfa_wino_selected(int ks, int Cout) { return ks == 3 && Cout >= g_cwfa_wino_min_cout; }
+
+// layers with more than 64 output channels take the 2-D F(2x2,3x3) kernel (conv_wino2d.hip) when "winograd_2d" is set
+extern int g_cwfa_wino_2d;
+static inline bool cwfa_wino2d_selected(int Cout) { return g_cwfa_wino_2d != 0 && Cout > 64; }
+int64_t cwfa_wino2d_packed_floats(int Cout, int Cin);
+int cwfa_wino2d_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream);
+int cwfa_wino2d_conv(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t x_bs,
+                     int64_t y_bs, const cwfa_conv_opts& o, hipStream_t stream);
 
 int64_t cwfa_wino_packed_floats(int Cout, int Cin);
 int cwfa_wino_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream);

@@ -629,12 +629,14 @@ int classify(const cwfa_conv_opts& o) {
 }  // namespace
 
 int64_t cwfa_wino_packed_floats(int Cout, int Cin) {
+    if (cwfa_wino2d_selected(Cout)) return cwfa_wino2d_packed_floats(Cout, Cin);
     const WSel s = wsel(Cout);
     const int64_t ctiles = (Cout + s.CT - 1) / s.CT, nchunks = (Cin + s.CK - 1) / s.CK;
     return ctiles * nchunks * 12 * s.CK * s.CT;
 }
 
 int cwfa_wino_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream) {
+    if (cwfa_wino2d_selected(Cout)) return cwfa_wino2d_pack(w, packed, Cout, Cin, stream);
     const WSel s = wsel(Cout);
     const int64_t total = cwfa_wino_packed_floats(Cout, Cin);
     const int nchunks = (Cin + s.CK - 1) / s.CK;
@@ -646,6 +648,7 @@ int cwfa_wino_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t
 
 int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t x_bs,
                    int64_t y_bs, const cwfa_conv_opts& o, hipStream_t stream) {
+    if (cwfa_wino2d_selected(Cout)) return cwfa_wino2d_conv(x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, o, stream);
     WParams p{};
     p.x = x; p.wp = w_packed; p.y = y;
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;

@@ -49,8 +49,11 @@ enum { CWFA_ACT_NONE = 0, CWFA_ACT_ELU = 1, CWFA_ACT_PRELU = 2, CWFA_ACT_GELU = 
 int cwfa_version(void);
 const char* cwfa_last_error(void);
 /* process-wide tuning options (set before packing weights; pack and launch consult the same value):
- *   "winograd_min_cout" : 3x3 convolutions with at least this many output channels use the Winograd F(2,3) kernels
- *                         (default 33; a value above every Cout selects the direct kernels everywhere).
+ *   "winograd_min_cout" : 3x3 convolutions with at least this many output channels use the Winograd kernels
+ *                         (default 1; a value above every Cout selects the direct kernels everywhere).
+ *   "winograd_2d"       : non-zero: layers with more than 64 output channels use the 2-D F(2x2,3x3) kernel
+ *                         (experimental: +1..13 % on plain convolutions, slower with a load-side prologue);
+ *                         0 (default): the 1-D F(2,3) kernel as for the narrower layers.
  * returns 0, or CWFA_E_INVAL for an unknown name. */
 int cwfa_set_option(const char* name, int value);
 

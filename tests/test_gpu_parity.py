@@ -175,7 +175,7 @@ def test_subnet_layer_fused_vs_torch_cpu(shape):
 @pytest.mark.parametrize("cfg", [
     # (B, Cin, H, W, Cout): 3x3 convs through the Winograd F(2,3) kernels (the default for every 3x3), all three tilings
     (1, 64, 16, 64, 64), (2, 29, 21, 37, 48), (1, 8, 9, 130, 40), (1, 70, 7, 63, 130), (1, 256, 8, 64, 128), (1, 6, 12, 66, 256),
-    (2, 29, 21, 37, 6), (1, 64, 16, 64, 24), (1, 5, 3, 3, 32),
+    (2, 29, 21, 37, 6), (1, 64, 16, 64, 24), (1, 5, 3, 3, 32), (2, 40, 13, 132, 96), (1, 16, 4, 64, 65),
 ])
 def test_conv3x3_winograd_vs_torch_cpu(cfg):
     from cwfa_amd import ops
@@ -191,8 +191,19 @@ def test_conv3x3_winograd_vs_torch_cpu(cfg):
     add = torch.randn(B, Cin, H, W, generator=g)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
-    ref_pro = F.prelu(F.conv2d(xin, w.double(), b.double(), padding=1), alpha.double())
+    lin_pro = F.conv2d(xin, w.double(), b.double(), padding=1)
+    ref_pro = F.prelu(lin_pro, alpha.double())
+    want = {"plain": ref, "elu": F.elu(ref), "prelu": F.prelu(ref, alpha.double()),
+            "res_prelu": F.prelu(ref + res.double(), alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
+            "pro_prelu": ref_pro, "pro_generic": F.elu(lin_pro)}
+    # Cout > 64: the 1-D F(2,3) W128 tiling (default) and the opt-in 2-D F(2x2,3x3) kernel
+    for two_d in ((0, 1) if Cout > 64 else (0,)):
+        _winograd_case(ops, two_d, x, w, b, res, alpha, sc, sh, add, want)
+
+
+def _winograd_case(ops, two_d, x, w, b, res, alpha, sc, sh, add, want):
     ops.set_option("winograd_min_cout", 1)
+    ops.set_option("winograd_2d", two_d)
     try:
         pc = ops.pack_conv_weight(w.cuda())
         got = {
@@ -203,14 +214,13 @@ def test_conv3x3_winograd_vs_torch_cpu(cfg):
             "generic": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="gelu", residual=res.cuda(), act2="relu"),
             "pro_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
                                     in_shift=sh.cuda(), in_add=add.cuda()),
+            "pro_generic": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="elu", in_scale=sc.cuda(), in_shift=sh.cuda(),
+                                      in_add=add.cuda()),
         }
     finally:
-        ops.set_option("winograd_min_cout", 1)
-    want = {"plain": ref, "elu": F.elu(ref), "prelu": F.prelu(ref, alpha.double()),
-            "res_prelu": F.prelu(ref + res.double(), alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
-            "pro_prelu": ref_pro}
+        ops.set_option("winograd_2d", 0)
     for k in want:
-        assert_close(got[k], want[k], 5e-6, f"winograd {k}")
+        assert_close(got[k], want[k], 5e-6, f"winograd (2-D {two_d}) {k}")
 
 
 def test_conv2d_generic_epilogue_combo():

@@ -12,13 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
-    "base": ("conv_wino.hip", []),
-    "d3": ("conv_wino.hip", ["-DCWFA_WDEPTH=3"]),
-    "d5": ("conv_wino.hip", ["-DCWFA_WDEPTH=5"]),
+    "base": ("conv_wino2d.hip", []),
+    "nostage": ("conv_wino2d.hip", ["-DCWFA_EXP_NOSTAGE"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
-    (64, 64, 512, 512, 3), (256, 256, 512, 512, 3), (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
-    (64, 96, 512, 512, 3)]
+    (256, 256, 512, 512, 3), (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
+]
 
 
 def build():
