@@ -717,3 +717,38 @@ extern "C" int cwfa_axpby_f32(const float* x, const float* z, float a, float b, 
     CWFA_LAUNCH_CHECK("cwfa_axpby_f32");
     return CWFA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ lenslet views
+// XLFMDatasetFull.extract_views (XLFMDataset.py:212-242) + the normalisation that follows it (CWFA.py:796-797):
+// view n is the sh x sw window centred on lenslet n, clipped to the sensor image; the clipped patch sits in the
+// BOTTOM-RIGHT corner of a zero-filled view (stacked_views[:, n, -ph:, -pw:] = patch), then (v - mean) / std everywhere.
+__global__ __launch_bounds__(256) void extract_views_kernel(const float* __restrict__ img, const int* __restrict__ coords,
+                                                            float* __restrict__ out, int Hs, int Ws, int nviews, int sh, int sw,
+                                                            float mean, float stdv, int64_t img_bs) {
+    const int n = blockIdx.y, b = blockIdx.z;
+    const int cy = coords[2 * n], cx = coords[2 * n + 1];
+    const int ly = max(cy - sh / 2, 0), lx = max(cx - sw / 2, 0);
+    const int uy = min(cy + sh / 2, Hs), ux = min(cx + sw / 2, Ws);
+    const int oy = sh - (uy - ly), ox = sw - (ux - lx);          // first output row / column holding image data
+    const float* ib = img + (int64_t)b * img_bs;
+    float* ob = out + ((int64_t)b * nviews + n) * sh * sw;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < sh * sw; e += gridDim.x * blockDim.x) {
+        const int i = e / sw, j = e % sw;
+        float v = 0.f;
+        if (i >= oy && j >= ox) v = ib[(int64_t)(ly + i - oy) * Ws + (lx + j - ox)];
+        ob[e] = (v - mean) / stdv;
+    }
+}
+
+extern "C" int cwfa_extract_views_f32(const float* image, const int* coords_yx, float* views, int B, int Hs, int Ws, int nviews,
+                                      int sh, int sw, float mean, float stdv, int64_t image_bs, void* stream) {
+    CWFA_REQUIRE(image && coords_yx && views, CWFA_E_INVAL, "cwfa_extract_views_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && nviews >= 0 && Hs > 0 && Ws > 0 && sh > 0 && sw > 0, CWFA_E_INVAL, "cwfa_extract_views_f32: bad size");
+    CWFA_REQUIRE(nviews <= 65535 && B <= 65535, CWFA_E_SHAPE, "cwfa_extract_views_f32: grid too large");
+    if (B == 0 || nviews == 0) return CWFA_OK;
+    const int per = (sh * sw + 255) / 256;
+    hipLaunchKernelGGL(extract_views_kernel, dim3(per < 256 ? per : 256, nviews, B), dim3(256), 0, (hipStream_t)stream, image,
+                       coords_yx, views, Hs, Ws, nviews, sh, sw, mean, stdv, image_bs);
+    CWFA_LAUNCH_CHECK("cwfa_extract_views_f32");
+    return CWFA_OK;
+}

@@ -446,6 +446,30 @@ def axpby(x, a, z=None, b=0.0):
     return out
 
 
+def extract_views(image, coords_yx, subimage_shape, mean=0.0, std=1.0):
+    """XLFMDatasetFull.extract_views (XLFMDataset.py:212-242) + (v - mean) / std (CWFA.py:796-797) in one launch.
+    image [B,1,Hs,Ws] fp32 on the HIP device; coords_yx: n x 2 integers (row, column) of the lenslet centres."""
+    L = _lib.lib()
+    image = _dev(image, "image")
+    if image.dim() != 4 or image.shape[1] != 1:
+        raise ValueError(f"extract_views: image must be [B,1,H,W], got {tuple(image.shape)}")
+    if image.dtype != torch.float32:
+        raise TypeError("extract_views: fp32 images only")
+    image = image if image[0].is_contiguous() else image.contiguous()
+    B, _, Hs, Ws = image.shape
+    co = torch.as_tensor(coords_yx, dtype=torch.int32).reshape(-1, 2)
+    sh, sw = int(subimage_shape[0]), int(subimage_shape[1])
+    ys, xs = co[:, 0], co[:, 1]
+    if len(co) and (bool(((torch.minimum(ys + sh // 2, torch.tensor(Hs)) - torch.clamp(ys - sh // 2, min=0)) <= 0).any()) or
+                    bool(((torch.minimum(xs + sw // 2, torch.tensor(Ws)) - torch.clamp(xs - sw // 2, min=0)) <= 0).any())):
+        raise ValueError("extract_views: a lenslet window lies outside the image")    # the reference raises on the empty patch
+    cod = co.contiguous().to(image.device)
+    out = torch.empty((B, len(co), sh, sw), dtype=torch.float32, device=image.device)
+    check(L.cwfa_extract_views_f32(_p(image), _p(cod), _p(out), B, Hs, Ws, len(co), sh, sw, float(mean), float(std),
+                                   image.stride(0), _stream()), "extract_views")
+    return out
+
+
 def set_option(name, value):
     """Process-wide tuning option of the library (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed
     before a change of "winograd_min_cout" must be re-packed."""

@@ -234,6 +234,14 @@ int cwfa_scale_channels_f32(const float* x, const float* scale_bc, float* y, int
 /* y = a*x + b*z (elementwise; z nullable) */
 int cwfa_axpby_f32(const float* x, const float* z, float a, float b, float* y, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Lenslet views (the step before the path): XLFMDatasetFull.extract_views XLFMDataset.py:212-242 followed by the
+ * normalisation of CWFA.py:796-797.  image [B,1,Hs,Ws] (batch stride image_bs), coords_yx int32 [nviews][2] (device),
+ * views [B,nviews,sh,sw]: window of sh x sw around each lenslet, clipped to the image, the clipped patch in the
+ * bottom-right corner of a zero view, then (v - mean) / stdv (mean 0, stdv 1 = the plain extraction). */
+int cwfa_extract_views_f32(const float* image, const int* coords_yx, float* views, int B, int Hs, int Ws, int nviews, int sh,
+                           int sw, float mean, float stdv, int64_t image_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

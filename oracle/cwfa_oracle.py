@@ -453,3 +453,19 @@ def inverse_pass(steps: Sequence[dict], low: Tensor, cond_input: Tensor, mean_ca
                           st.get("n_blocks", 4), st.get("use_perm", True))
         vols.append(up)
     return vols
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Lenslet views
+def extract_views(image: Tensor, coords_yx, subimage_shape, mean: float = 0.0, std: float = 1.0) -> Tensor:
+    """XLFMDatasetFull.extract_views XLFMDataset.py:212-242, then (v - mean) / std (CWFA.py:796-797).
+    Window of subimage_shape around each lenslet, lower bounds clamped to 0 (:236-237), upper bounds clipped by slicing
+    (:238), the clipped patch written into the bottom-right corner of a zero view (:239)."""
+    sh, sw = int(subimage_shape[0]), int(subimage_shape[1])
+    hh, hw = sh // 2, sw // 2
+    out = torch.zeros((image.shape[0], len(coords_yx), sh, sw), dtype=image.dtype)
+    for n, (cy, cx) in enumerate(coords_yx):
+        cy, cx = int(cy), int(cx)
+        patch = image[:, 0, max(cy - hh, 0): cy + hh, max(cx - hw, 0): cx + hw]
+        out[:, n, sh - patch.shape[1]:, sw - patch.shape[2]:] = patch
+    return (out - mean) / std

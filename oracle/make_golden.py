@@ -22,6 +22,7 @@ Fixture index:
   g09_step_<bt>_k<k> one full GraphINN step per block type    (networks.py:264-368)
   g10_pipeline      2-step inverse pipeline + evaluate_INN_forward (CWFA.py:134-196,865-924)
   g11_unet_*, g11_convnext, g11_attention, g11_lrnn_small, g11_lrnn_full
+  g12_extract_views_*   XLFMDatasetFull.extract_views (needs only torch: imported from the reference file directly)
 """
 import os
 import sys
@@ -343,5 +344,28 @@ def main():
          seed_init=np.int64(41), seed_input=np.int64(4343), seed_ln=np.int64(4444))
 
 
+def gen_extract_views():
+    """g12: the reference's XLFMDatasetFull.extract_views on small frames, windows clipped at every border."""
+    import_reference()
+    import torch
+    from XLFMDataset import XLFMDatasetFull
+    g = torch.Generator().manual_seed(12)
+    cases = {
+        "even": ((2, 1, 40, 50), (16, 16), [(20, 25), (3, 4), (38, 47), (8, 45), (33, 2), (0, 1), (39, 49)]),
+        "odd": ((1, 1, 31, 29), (15, 9), [(15, 14), (2, 1), (30, 28), (7, 3)]),
+        "wide": ((1, 1, 24, 90), (8, 64), [(12, 45), (1, 10), (22, 80)]),
+    }
+    for name, (ishape, sub, coords) in cases.items():
+        img = torch.randn(*ishape, generator=g)
+        views = XLFMDatasetFull.extract_views(img, coords, list(sub), debug=False)
+        mean, std = 0.37, 1.9
+        dump(f"g12_extract_views_{name}", image=npy(img), coords=np.asarray(coords, dtype=np.int64), sub=np.asarray(sub),
+             views=npy(views), normalized=npy((views - mean) / std), mean=np.float32(mean), std=np.float32(std))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extract_views":
+        gen_extract_views()
+    else:
+        main()
+        gen_extract_views()

@@ -543,3 +543,30 @@ def test_full_size_step_roundtrip():
     xr, jr = g([z, low], c=c, rev=True)
     assert float((xr - x).abs().max()) <= 1e-4 * float(x.abs().max())
     assert abs(float(jf + jr)) <= 1e-4 * abs(float(jf))
+
+
+# ------------------------------------------------------------------------------------------------ lenslet views (8f row 2)
+@pytest.mark.parametrize("name", ["even", "odd", "wide"])
+def test_extract_views_golden(name):
+    from cwfa_amd import ops
+    from cwfa_amd.XLFMDataset import XLFMDatasetFull
+    fx = load_golden(f"g12_extract_views_{name}")
+    img, coords, sub = torch.from_numpy(fx["image"]).cuda(), fx["coords"].tolist(), fx["sub"].tolist()
+    assert np.array_equal(XLFMDatasetFull.extract_views(img, coords, sub).cpu().numpy(), fx["views"])
+    got = XLFMDatasetFull.extract_views_normalized(img, coords, sub, float(fx["mean"]), float(fx["std"]))
+    assert np.array_equal(got.cpu().numpy(), fx["normalized"])
+    with pytest.raises(ValueError, match="outside the image"):
+        ops.extract_views(img, [(-40, 3)], sub)
+
+
+def test_extract_views_full_frame_vs_oracle():
+    """The real geometry: 29 views of 512x512 out of a 2160x2160 frame (30 MB out), against the CPU oracle."""
+    from cwfa_amd import ops
+    from oracle import cwfa_oracle as O
+    g = torch.Generator().manual_seed(29)
+    img = torch.randn(1, 1, 2160, 2160, generator=g)
+    coords = torch.randint(100, 2060, (29, 2), generator=g).tolist()
+    coords[0], coords[1] = (120, 2100), (2150, 300)               # clipped at two borders
+    ref = O.extract_views(img, coords, (512, 512), 0.1, 2.5)
+    got = ops.extract_views(img.cuda(), coords, (512, 512), 0.1, 2.5)
+    assert np.array_equal(got.cpu().numpy(), ref.numpy())

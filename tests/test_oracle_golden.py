@@ -192,3 +192,12 @@ def test_convnext_attention():
     assert_close(O.convnext(sd_of(fx), "", T(fx["x"])), fx["y"], 1e-5)
     fx = load_golden("g11_attention")
     assert_close(O.global_attention(sd_of(fx), "", T(fx["x"])), fx["y"], TOL)
+
+
+@pytest.mark.parametrize("name", ["even", "odd", "wide"])
+def test_extract_views(name):
+    """the lenslet crop in front of the path; bit-exact (it is a gather + one fp32 sub/div)."""
+    fx = load_golden(f"g12_extract_views_{name}")
+    img, coords, sub = T(fx["image"]), fx["coords"].tolist(), fx["sub"].tolist()
+    assert np.array_equal(O.extract_views(img, coords, sub).numpy(), fx["views"])
+    assert np.array_equal(O.extract_views(img, coords, sub, float(fx["mean"]), float(fx["std"])).numpy(), fx["normalized"])
