@@ -121,3 +121,34 @@ def test_install_aliases():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """the reference's checkpoint files (networks.py:708-756): file naming, dict keys, discovery
+    of the newest epoch per step, and state_dicts that load back into freshly built nets."""
+    import argparse
+    torch.manual_seed(0)
+    np.random.seed(0)
+    build = lambda: N.conditional_wavelet_flow([8, 8, 8], [1, 29, 8, 8], N.wavelet_flow_subnetwork2D,
+                                               lambda: N.cond_network(29, 4, 1, 3, [], 4), n_internal_ch=8, n_down_steps=1,
+                                               use_permutations=True, block_type="CAT", n_blocks=2)
+    cond, inns = build()
+    args = argparse.Namespace(INN_down_steps=0, lr=1e-3)
+    stats = (0.1, 1.5, 0.0, 1.0, 0.2, 2.0)
+    for ep in (3, 11, 7):
+        N.serialize_INN_step(inns[0], cond[0] if isinstance(cond, (list, tuple)) else cond, None, stats, args, ep, str(tmp_path))
+    args.INN_down_steps = 1
+    N.serialize_INN_step(None, None, None, stats, args, 5, str(tmp_path), posfix="")
+    found = N.load_INN_steps(str(tmp_path))
+    assert sorted(found) == [0, 1] and found[0][0] == 11 and found[1][0] == 5
+    assert found[0][1].endswith("model_step_0__ep_11")
+    assert N.load_INN_steps(str(tmp_path), epoch=7)[0][0] == 7
+    ck = torch.load(found[0][1], weights_only=False)          # our own file (argparse.Namespace inside, as the reference writes)
+    assert set(ck) == {"epoch", "args", "INN_state_dict", "condition_state_dict", "optimizer_state_dict", "training_statistics"}
+    torch.manual_seed(1)
+    np.random.seed(0)                                          # permutations come from numpy's global RNG: same graph
+    cond2, inns2 = build()
+    inns2[0].load_state_dict(ck["INN_state_dict"])
+    for (k, a), (_, b) in zip(inns[0].state_dict().items(), inns2[0].state_dict().items()):
+        assert torch.equal(a, b), k
+    assert ck["training_statistics"] == stats and ck["optimizer_state_dict"] is None
