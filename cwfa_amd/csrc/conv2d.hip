@@ -44,6 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CWFA_CK3
 #define CWFA_CK3 8
 #endif
+#ifndef CWFA_CK1
+#define CWFA_CK1 16
+#endif
 
 namespace {
 
@@ -586,12 +589,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 typedef Cfg<3, CWFA_CK3, 1, 4, 1, 4> C3_32;                        // Cout <= 32 : 32 ch x 16 rows x 32 cols
 typedef Cfg<3, CWFA_CK3, 2, 2, 1, CWFA_WN64> C3_64;                // Cout <= 64 : 64 ch x 2*WN rows x 32 cols
 typedef Cfg<3, CWFA_CK3, 2, 2, CWFA_WM128, CWFA_WN128> C3_128;     // Cout  > 64 : 64*WM ch x 2*WN rows x 32 cols
-typedef Cfg<1, 16, 1, 4, 1, 4> C1_32;
-typedef Cfg<1, 16, 2, 2, 1, CWFA_WN64> C1_64;
-typedef Cfg<1, 16, 2, 2, CWFA_WM128, CWFA_WN128> C1_128;
-typedef Cfg<1, 16, 1, 4, 1, 4, 4> C1v_32;                           // the same tiles staged 16 bytes per lane
-typedef Cfg<1, 16, 2, 2, 1, CWFA_WN64, 4> C1v_64;
-typedef Cfg<1, 16, 2, 2, CWFA_WM128, CWFA_WN128, 4> C1v_128;
+typedef Cfg<1, CWFA_CK1, 1, 4, 1, 4> C1_32;
+typedef Cfg<1, CWFA_CK1, 2, 2, 1, CWFA_WN64> C1_64;
+typedef Cfg<1, CWFA_CK1, 2, 2, CWFA_WM128, CWFA_WN128> C1_128;
+typedef Cfg<1, CWFA_CK1, 1, 4, 1, 4, 4> C1v_32;                           // the same tiles staged 16 bytes per lane
+typedef Cfg<1, CWFA_CK1, 2, 2, 1, CWFA_WN64, 4> C1v_64;
+typedef Cfg<1, CWFA_CK1, 2, 2, CWFA_WM128, CWFA_WN128, 4> C1v_128;
 typedef Cfg<7, 4, 1, 4, 1, 4> C7_32;
 typedef Cfg<7, 4, 2, 2, 1, 8> C7_64;
 

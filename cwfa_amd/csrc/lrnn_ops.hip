@@ -3,18 +3,36 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ BatchNorm statistics
-// grid (splits, C): each block sums a slice of the (B, HW) elements of channel c and adds (sum, sumsq) in double.
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int B,
-                                                            int64_t HW, int64_t x_bs) {
+// grid (splits, C, B): each block sums a contiguous slice of one (sample, channel) plane and adds (sum, sumsq) in double.
+// Per thread the partial sums of <= 64 elements stay in fp32 pairs feeding doubles (the products are exact in double).
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int64_t HW,
+                                                            int64_t x_bs, int vec_ok) {
     __shared__ double red[16];
     const int c = blockIdx.y;
-    const int64_t total = (int64_t)B * HW;
+    const float* p = x + (int64_t)blockIdx.z * x_bs + (int64_t)c * HW;
+    const int64_t per = (((HW + gridDim.x - 1) / gridDim.x) + 3) & ~(int64_t)3;      // slices start on 16-byte boundaries
+    const int64_t lo = (int64_t)blockIdx.x * per < HW ? (int64_t)blockIdx.x * per : HW, hi = lo + per < HW ? lo + per : HW;
     double s = 0.0, q = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / HW, p = i - b * HW;
-        const float v = x[b * x_bs + (int64_t)c * HW + p];
-        s += v;
-        q += (double)v * v;
+    if (vec_ok && (lo & 3) == 0) {
+        const int64_t n4 = (hi - lo) >> 2;
+        const cs_f4* p4 = reinterpret_cast<const cs_f4*>(p + lo);
+        for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+            const cs_f4 v = p4[i];
+            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            q += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+        }
+        for (int64_t i = lo + (n4 << 2) + threadIdx.x; i < hi; i += blockDim.x) {
+            const float v = p[i];
+            s += v;
+            q += (double)v * v;
+        }
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const float v = p[i];
+            s += v;
+            q += (double)v * v;
+        }
     }
     s = cwfa_block_sum(s, red);
     q = cwfa_block_sum(q, red);
@@ -26,13 +44,13 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 extern "C" int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream) {
     CWFA_REQUIRE(x && stats, CWFA_E_INVAL, "cwfa_channel_stats_f32: null pointer");
-    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C <= 65535, CWFA_E_SHAPE, "cwfa_channel_stats_f32: bad shape");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C <= 65535 && B <= 65535, CWFA_E_SHAPE, "cwfa_channel_stats_f32: bad shape");
     if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
-    const int64_t total = (int64_t)B * HW;
-    int splits = (int)((total + 256 * 16 - 1) / (256 * 16));
+    int splits = (int)((HW + 256 * 16 - 1) / (256 * 16));          // >= 16 elements per thread
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(splits, C), dim3(256), 0, (hipStream_t)stream, x, stats, B, HW, x_bs);
+    const int vec_ok = (HW & 3) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(splits, C, B), dim3(256), 0, (hipStream_t)stream, x, stats, HW, x_bs, vec_ok);
     CWFA_LAUNCH_CHECK("cwfa_channel_stats_f32");
     return CWFA_OK;
 }

@@ -570,3 +570,15 @@ def test_extract_views_full_frame_vs_oracle():
     ref = O.extract_views(img, coords, (512, 512), 0.1, 2.5)
     got = ops.extract_views(img.cuda(), coords, (512, 512), 0.1, 2.5)
     assert np.array_equal(got.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 3, 64, 64), (2, 4, 33, 100), (1, 2, 300, 300)])
+def test_channel_stats_vs_torch(shape):
+    """BatchNorm batch statistics (sum, sum of squares per channel, float64), contiguous and channel-sliced inputs."""
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 3 + 1
+    for xv in (x, torch.cat([x, x], 1)[:, :shape[1]]):
+        st = ops.channel_stats(xv.cuda()).cpu().view(shape[1], 2)
+        ref = torch.stack([xv.double().sum((0, 2, 3)), (xv.double() ** 2).sum((0, 2, 3))], 1)
+        assert float((st - ref).abs().max() / ref.abs().max()) < 1e-12

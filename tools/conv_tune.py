@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
-    "base": ("conv_wino2d.hip", []),
-    "nostage": ("conv_wino2d.hip", ["-DCWFA_EXP_NOSTAGE"]),
+    "base": ("conv2d.hip", []),
+    "ck32": ("conv2d.hip", ["-DCWFA_CK1=32"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
-    (256, 256, 512, 512, 3), (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
+    (1024, 2048, 128, 128, 1), (512, 1024, 256, 256, 1), (64, 64, 512, 512, 1), (256, 8, 512, 512, 1),
 ]
 
 
