@@ -62,6 +62,7 @@ SIGNATURES = {
     "cwfa_attention_combine_f32": (i, [p, p, p, p, p, p, p, p, i, i, i64, p]),
     "cwfa_scale_channels_f32": (i, [p, p, p, i, i, i64, p]),
     "cwfa_axpby_f32": (i, [p, p, f, f, p, i64, p]),
+    "cwfa_bn_running_update_f32": (i, [p, C.c_double, f, p, p, p, i, p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

@@ -87,6 +87,30 @@ __global__ void bn_fold_kernel(const double* __restrict__ stats, double count, c
     }
 }
 
+// nn.BatchNorm2d's train-mode buffer bookkeeping in one launch (torch/nn/modules/batchnorm.py via unet.py:101-107):
+// running_mean <- (1-m) running_mean + m mean,  running_var <- (1-m) running_var + m var_unbiased,  num_batches_tracked += 1
+__global__ void bn_running_update_kernel(const double* __restrict__ stats, double count, float momentum, float* __restrict__ rm,
+                                         float* __restrict__ rv, long long* __restrict__ nbt, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double mean = stats[2 * c] / count;
+    const double var_u = (stats[2 * c + 1] - stats[2 * c] * mean) / (count > 1.0 ? count - 1.0 : 1.0);
+    rm[c] = rm[c] * (1.f - momentum) + momentum * (float)mean;
+    rv[c] = rv[c] * (1.f - momentum) + momentum * (float)var_u;
+}
+
+extern "C" int cwfa_bn_running_update_f32(const double* stats, double count, float momentum, float* running_mean,
+                                          float* running_var, long long* num_batches_tracked, int C, void* stream) {
+    CWFA_REQUIRE(stats && running_mean && running_var, CWFA_E_INVAL, "cwfa_bn_running_update_f32: null pointer");
+    CWFA_REQUIRE(C >= 0 && count > 0.0, CWFA_E_INVAL, "cwfa_bn_running_update_f32: bad size");
+    if (C == 0) return CWFA_OK;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count, momentum,
+                       running_mean, running_var, num_batches_tracked, C);
+    CWFA_LAUNCH_CHECK("cwfa_bn_running_update_f32");
+    return CWFA_OK;
+}
+
 extern "C" int cwfa_bn_fold_f32(const double* stats, double count, const float* running_mean, const float* running_var,
                                 const float* weight, const float* bias, float eps, const float* mask_bc, int B, float* scale,
                                 float* shift, int C, void* stream) {

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "pack_1x1_panel", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "pack_1x1_panel", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -366,6 +366,13 @@ def channel_stats(x):
     st = torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
     check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
     return st
+
+
+def bn_running_update(stats, count, momentum, running_mean, running_var, num_batches_tracked=None):
+    """nn.BatchNorm2d's train-mode update of its buffers from channel_stats() sums, in place, one launch."""
+    L = _lib.lib()
+    check(L.cwfa_bn_running_update_f32(_p(stats), float(count), float(momentum), _p(_dev(running_mean)), _p(_dev(running_var)),
+                                       _p(num_batches_tracked), running_mean.numel(), _stream()), "bn_running_update")
 
 
 def bn_fold(C_, weight=None, bias=None, eps=1e-5, stats=None, count=0.0, running_mean=None, running_var=None,

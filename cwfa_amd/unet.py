@@ -43,13 +43,7 @@ def _bn_affine(bn, y, mask_bc=None):
         st = ops.channel_stats(y)
         n = y.numel() // C
         if bn.track_running_stats and bn.momentum is not None:       # buffer bookkeeping, as nn.BatchNorm2d does
-            with torch.no_grad():
-                s2 = st.view(C, 2)
-                mean = s2[:, 0] / n
-                var_u = (s2[:, 1] - s2[:, 0] * mean) / max(n - 1, 1)
-                bn.running_mean.mul_(1 - bn.momentum).add_(mean.to(torch.float32), alpha=bn.momentum)
-                bn.running_var.mul_(1 - bn.momentum).add_(var_u.to(torch.float32), alpha=bn.momentum)
-                bn.num_batches_tracked += 1
+            ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
         return ops.bn_fold(C, bn.weight, bn.bias, bn.eps, stats=st, count=float(n), mask_bc=mask_bc)
     return ops.bn_fold(C, bn.weight, bn.bias, bn.eps, running_mean=bn.running_mean, running_var=bn.running_var,
                        mask_bc=mask_bc)

@@ -215,6 +215,10 @@ int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t 
 int cwfa_bn_fold_f32(const double* stats, double count, const float* running_mean, const float* running_var,
                      const float* weight, const float* bias, float eps, const float* mask_bc, int B, float* scale,
                      float* shift, int C, void* stream);
+/* train-mode buffer bookkeeping of nn.BatchNorm2d (unet.py:101-107) from the same statistics: running_mean/var updated
+ * with `momentum` (unbiased variance), num_batches_tracked (int64, nullable) incremented. */
+int cwfa_bn_running_update_f32(const double* stats, double count, float momentum, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, int C, void* stream);
 /* F.adaptive_max_pool2d(x, (Ho,Wo)) (unet.py:79) with an optional per-channel affine applied BEFORE the max
  * (the producer's BatchNorm); also writes the affine result at full resolution to `full` (nullable; the skip). */
 int cwfa_maxpool_f32(const float* x, float* y, float* full, const float* scale, const float* shift, int B, int C,

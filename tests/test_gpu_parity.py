@@ -582,3 +582,20 @@ def test_channel_stats_vs_torch(shape):
         st = ops.channel_stats(xv.cuda()).cpu().view(shape[1], 2)
         ref = torch.stack([xv.double().sum((0, 2, 3)), (xv.double() ** 2).sum((0, 2, 3))], 1)
         assert float((st - ref).abs().max() / ref.abs().max()) < 1e-12
+
+
+def test_bn_running_update_matches_torch_batchnorm():
+    """Train-mode buffer bookkeeping (running mean / unbiased running var / num_batches_tracked) vs nn.BatchNorm2d on CPU."""
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 6, 9, 11, generator=g) * 2 + 0.5
+    ref = torch.nn.BatchNorm2d(6, momentum=0.1)
+    ref.running_mean.copy_(torch.randn(6, generator=g))
+    ref.running_var.copy_(torch.rand(6, generator=g) + 0.5)
+    rm, rv, nbt = ref.running_mean.clone().cuda(), ref.running_var.clone().cuda(), ref.num_batches_tracked.clone().cuda()
+    ref.train()(x)
+    st = ops.channel_stats(x.cuda())
+    ops.bn_running_update(st, x.numel() // 6, 0.1, rm, rv, nbt)
+    assert_close(rm, ref.running_mean, 1e-6)
+    assert_close(rv, ref.running_var, 1e-6)
+    assert int(nbt) == int(ref.num_batches_tracked) == 1
