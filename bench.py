@@ -105,10 +105,18 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     import torch.distributed as dist
+    # rehearsal switch (not used by the driver): several ranks on ONE card over gloo, to exercise the N > 1 control flow
+    # on a single-GPU box (RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("CWFA_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     from cwfa_amd import CWFA, ops
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN

@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
     const int dummy = C::NWAVES * C::OS + tid;                 // per-lane sink for masked-off contributions
     const int gw = w0 - 1 + wl;
     const bool in_w = gw >= 0 && gw < W;
+    const bool alpha_le1 = alpha >= 0.f && alpha <= 1.f;                     // wave-uniform
+    const bool w_edge = w0 - 1 < 0 || w0 - 1 + 31 >= W;                      // block-uniform: some hidden columns are padding
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 Pp = zero16;          // conv2 products of the previous row, scattered under the next row's conv1 MFMAs
     int pbase = 0, pmask = 0;
@@ -241,11 +243,17 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 14; ++j) hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], xv[j], hid, 0, 0, 0);
         scatter(Pp, pbase, pmask);
+        // PReLU: max(v, alpha v) for 0 <= alpha <= 1 (2 instructions); the column mask only where the row leaves the volume
+        if (alpha_le1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = hid[r];
-            v = v > 0.f ? v : alpha * v;
-            hid[r] = in_w ? v : 0.f;
+            for (int r = 0; r < 16; ++r) hid[r] = fmaxf(hid[r], alpha * hid[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[r] = hid[r] > 0.f ? hid[r] : alpha * hid[r];
+        }
+        if (w_edge) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[r] = in_w ? hid[r] : 0.f;
         }
         f32x16 P = zero16;
 #pragma unroll
