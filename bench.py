@@ -90,7 +90,7 @@ def conv_bytes(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="volumes per step per GPU")
     ap.add_argument("--side", type=int, default=512)
