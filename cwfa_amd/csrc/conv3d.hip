@@ -118,17 +118,22 @@ __global__ __launch_bounds__(256) void conv3d_1k1_kernel(const float* __restrict
 //   conv2:  P[tap][w]    = sum_k w2[k][tap] * hidden[k][w]                    M = tap (27 of 32), K = 32 channels (16 MFMAs;
 //           conv1's accumulator registers ARE conv2's B operand: register r of lane (w, kh) holds channel rc(r)+4kh,
 //           which is the k-pair layout the instruction wants)
-// and P[tap][w] is the contribution of hidden voxel (d',h',w) to output voxel (d'-dd, h'-dh, w-dw): it is scattered with
-// ds_add_f32 into a per-wave private copy of the output tile (fixed program order => deterministic), the four copies
-// are summed at the end.  Block = 6 x 8 x 30 output voxels; the +1 hidden halo makes rows exactly 32 wide.
+// and P[tap][w] is the contribution of hidden voxel (d',h',w) to output voxel (d'-dd, h'-dh, w-dw): it is scattered by LDS
+// read-modify-write into a PADDED per-wave private copy of the output tile (fixed program order => deterministic; LDS
+// float atomics were 2x slower; the padding absorbs out-of-tile targets so the scatter needs no validity tests), and every
+// output slab is the sum of exactly two private copies.  Block = 6 x 8 x 30 output voxels; the +1 hidden halo makes rows exactly 32 wide.
 struct C3M {
     static constexpr int DT = 6, HT = 8, WT = 30, NTHREADS = 256, NWAVES = 4;
     static constexpr int XD = DT + 4, XH = HT + 4, XW = 36;     // staged input (origin -2), 34 used columns
     static constexpr int HD = DT + 2, HH = HT + 2;               // hidden rows (origin -1), 32 columns
-    static constexpr int XS = XD * XH * XW, OS = DT * HT * 32;
+    static constexpr int XS = XD * XH * XW;
+    // per-wave private output copy, padded so that NO scatter target needs a validity test: 4 depth slabs (a wave owns two
+    // hidden slabs), HT + 4 rows, 32 + 2 (+2 pad) columns; contributions that fall outside the tile land in the padding
+    static constexpr int PS = 4, PH = HT + 4, PW = 36, OS = PS * PH * PW;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_c3 __attribute__((ext_vector_type(4)));
 
 // batch of tap t in the scatter (found by exhaustive search: 10 of the 12 two-tap registers keep both halves together)
 __host__ __device__ constexpr int c3m_batch(int t) {
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
                                                               int tiles_w) {
     typedef C3M C;
     __shared__ float Xs[C::XS];
-    __shared__ float Os[C::NWAVES * C::OS + C::NTHREADS];
+    __shared__ __attribute__((aligned(16))) float Os[C::NWAVES * C::OS + C::NTHREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wl = lane & 31, kh = lane >> 5;
     const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
     const int d0 = blockIdx.y * C::DT, h0 = th * C::HT, w0 = tw * C::WT, b = blockIdx.z;
@@ -168,13 +173,13 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
         for (int i = 0; i < NI; ++i)
             if (tid + i * C::NTHREADS < C::XS) Xs[tid + i * C::NTHREADS] = v[i];
     }
-    for (int e = tid; e < C::NWAVES * C::OS; e += C::NTHREADS) Os[e] = 0.f;
+    for (int e = tid; e < C::NWAVES * C::OS / 4; e += C::NTHREADS) reinterpret_cast<f32x4_c3*>(Os)[e] = f32x4_c3{0.f, 0.f, 0.f, 0.f};
 
     // operand panels, resident in registers for the whole block.  conv1's bias rides on the unused 28th tap
-    // (MFMA 13, k-slot 1: A = b1[k], B = 1).  pk[r] = where accumulator register r of this lane scatters to, relative
-    // to the hidden row, plus (bits 16..) which bit of the per-row validity mask guards it (31 = never).
+    // (MFMA 13, k-slot 1: A = b1[k], B = 1).  relp[r] = where accumulator register r of this lane scatters to, relative
+    // to the hidden row's base cell in the wave's padded private copy.
     float a1[14], a2[16];
-    int toff[14], pk[16];
+    int toff[14], relp[16];
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
         const int tap = 2 * j + kh;
@@ -189,26 +194,24 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
         const int k = (r & 3) + 8 * (r >> 2) + 4 * kh;
         const float w2v = w2[min(k, K - 1) * 27 + min(wl, 26)];
         a2[r] = (k < K && wl < 27) ? w2v : 0.f;
-        const int tap = k;                                     // same index formula: row of P held by (r, kh)
-        const int dd = tap % 3, dw = (tap / 3) % 3, dh = tap / 9, ow = wl - dw;
-        const bool valid = tap < 27 && ow >= 0 && ow < C::WT;
-        pk[r] = ((-dd * C::HT - dh) * 32 + ow + 1024) | ((valid ? dd + 3 * dh : 31) << 16);
+        const int tap = k < 27 ? k : 0;                        // same index formula: row of P held by (r, kh)
+        const int dd = tap % 3, dw = (tap / 3) % 3, dh = tap / 9;
+        relp[r] = (-dd * C::PH - dh) * C::PW + wl - dw;
     }
     __syncthreads();
 
-    float* Ow = Os + wave * C::OS;
-    const int dummy = C::NWAVES * C::OS + tid;                 // per-lane sink for masked-off contributions
+    const int dummy = C::NWAVES * C::OS + tid;                 // per-lane sink for the lanes that sit out a batch
     const int gw = w0 - 1 + wl;
     const bool in_w = gw >= 0 && gw < W;
     const bool alpha_le1 = alpha >= 0.f && alpha <= 1.f;                     // wave-uniform
     const bool w_edge = w0 - 1 < 0 || w0 - 1 + 31 >= W;                      // block-uniform: some hidden columns are padding
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 Pp = zero16;          // conv2 products of the previous row, scattered under the next row's conv1 MFMAs
-    int pbase = 0, pmask = 0;
+    int pbase = wave * C::OS + (2 * C::PH + 2) * C::PW + 2;
     // LDS read-modify-write in three alias-free batches: two contributions can only meet in one output voxel when their
     // taps share (dd, dh) and differ in dw, so a batch takes at most one tap of each (dd, dh) triple (c3m_batch) and its
-    // reads can all be in flight before its writes.  Lanes whose half is not in the batch (or masked off) hit the sink.
-    auto scatter = [&](const f32x16& P, int base, int mask) {
+    // reads can all be in flight before its writes.  A lane half that is not in the batch goes to the sink.
+    auto scatter = [&](const f32x16& P, int base) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float old[15];
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
                 const int t0 = (r & 3) + 8 * (r >> 2);
                 const bool h0 = c3m_batch(t0) == c, h1 = c3m_batch(t0 + 4) == c;
                 if (!h0 && !h1) continue;
-                const bool mine = kh ? h1 : h0;
-                at[r] = (mine && ((mask >> (pk[r] >> 16)) & 1)) ? base + (pk[r] & 0xffff) : dummy;
+                at[r] = base + relp[r];
+                if (!(h0 && h1)) at[r] = (kh ? h1 : h0) ? at[r] : dummy;
                 old[r] = Os[at[r]];
             }
 #pragma unroll
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
             }
         }
     };
-    for (int row = wave; row < C::HD * C::HH; row += C::NWAVES) {
-        const int dp = row / C::HH, hp = row % C::HH;
+    // wave w owns the hidden slabs d' = 2w, 2w+1 (all HH rows each)
+    for (int i = 0; i < 2 * C::HH; ++i) {
+        const int dl = i / C::HH, hp = i % C::HH, dp = 2 * wave + dl;
         const int gd = d0 - 1 + dp, gh = h0 - 1 + hp;
         if (gd < 0 || gd >= D || gh < 0 || gh >= H) continue;      // hidden row is conv2's zero padding (wave-uniform)
         const float* xr = Xs + (dp * C::XH + hp) * C::XW + wl;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
         f32x16 hid = zero16;
 #pragma unroll
         for (int j = 0; j < 14; ++j) hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], xv[j], hid, 0, 0, 0);
-        scatter(Pp, pbase, pmask);
+        scatter(Pp, pbase);
         // PReLU: max(v, alpha v) for 0 <= alpha <= 1 (2 instructions); the column mask only where the row leaves the volume
         if (alpha_le1) {
 #pragma unroll
@@ -259,25 +263,21 @@ __global__ __launch_bounds__(256) void conv3d_1k1_mfma_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) P = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], hid[r], P, 0, 0, 0);
         Pp = P;
-        pbase = wave * C::OS + (dp * C::HT + hp) * 32 - 1024;
-        int m = 0;
-#pragma unroll
-        for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd)
-                if ((unsigned)(dp - dd) < (unsigned)C::DT && (unsigned)(hp - dh) < (unsigned)C::HT) m |= 1 << (dd + 3 * dh);
-        pmask = m;
+        pbase = wave * C::OS + ((dl + 2) * C::PH + hp + 2) * C::PW + 2;
     }
-    scatter(Pp, pbase, pmask);
-    (void)Ow;
+    scatter(Pp, pbase);
     __syncthreads();
     const float bb = b2[0];
-    for (int e = tid; e < C::OS; e += C::NTHREADS) {
+    // output slab od collects exactly two private copies: wave od/2 (its slab (od&1)+2) and wave od/2+1 (its slab od&1)
+    for (int e = tid; e < C::DT * C::HT * 32; e += C::NTHREADS) {
         const int ow = e & 31, oh = (e >> 5) % C::HT, od = e / (32 * C::HT);
         const int gdo = d0 + od, gho = h0 + oh, gwo = w0 + ow;
-        if (ow < C::WT && gdo < D && gho < H && gwo < W)
-            y[(int64_t)b * D * HW + (int64_t)gdo * HW + (int64_t)gho * W + gwo] =
-                ((Os[e] + Os[C::OS + e]) + (Os[2 * C::OS + e] + Os[3 * C::OS + e])) + bb;
+        if (ow < C::WT && gdo < D && gho < H && gwo < W) {
+            const int wa = od >> 1, cell = (oh + 2) * C::PW + ow + 2;
+            const float va = Os[wa * C::OS + ((od & 1) + 2) * C::PH * C::PW + cell];
+            const float vb = Os[(wa + 1) * C::OS + (od & 1) * C::PH * C::PW + cell];
+            y[(int64_t)b * D * HW + (int64_t)gdo * HW + (int64_t)gho * W + gwo] = (va + vb) + bb;
+        }
     }
 }
 

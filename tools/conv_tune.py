@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
-    "base": ("conv2d.hip", []),
-    "ck32": ("conv2d.hip", ["-DCWFA_CK1=32"]),
+    "novload": ("conv_wino2d.hip", ["-DCWFA_EXP_NOVLOAD"]),
+    "novload_noxform": ("conv_wino2d.hip", ["-DCWFA_EXP_NOVLOAD", "-DCWFA_EXP_NOXFORM"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
-    (1024, 2048, 128, 128, 1), (512, 1024, 256, 256, 1), (64, 64, 512, 512, 1), (256, 8, 512, 512, 1),
+    (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
 ]
 
 
@@ -41,6 +41,7 @@ def run_one(name):
     from cwfa_amd import _lib
     _lib.LIB_PATH = os.path.join(VDIR, f"lib_{name}.so")
     from cwfa_amd import ops
+    ops.set_option("winograd_2d", int(os.environ.get("CWFA_TUNE_2D", "1")))
     res = {}
     for (cin, cout, H, W, ks) in SHAPES:
         x = torch.randn(1, cin, H, W, device="cuda")
