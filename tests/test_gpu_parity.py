@@ -599,3 +599,33 @@ def test_bn_running_update_matches_torch_batchnorm():
     assert_close(rm, ref.running_mean, 1e-6)
     assert_close(rv, ref.running_var, 1e-6)
     assert int(nbt) == int(ref.num_batches_tracked) == 1
+
+
+def test_full_config3_inverse_vs_oracle():
+    """BASELINE.json configs[2] at FULL size -- 512x512x96, LRNN (train-mode BatchNorm as CWFA.py:532) + 4 flow steps with
+    their condition nets, default-init weights -- against the CPU oracle on identical inputs.  The stochastic layers
+    (dropout2d, drop_path) are switched off on both sides; everything else is the benchmark's path.  ~20-60 s of CPU."""
+    from cwfa_amd import CWFA
+    from oracle import cwfa_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 5, with_lrnn=True, device="cuda")
+    enc = cond_nets[-1]
+    enc.net.deconv[1].drop_out = 0
+    for cn in enc.net.conv3d:
+        cn.drop_prob = 0.0
+    g = torch.Generator().manual_seed(1)
+    cond_input = torch.randn(1, 29, 512, 512, generator=g)
+    mean_cache = [0.1 * torch.randn(1, 96 // 2 ** (n + 1), 512, 512, generator=g) for n in range(4)]
+    with torch.no_grad():
+        out = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache])
+    torch.cuda.synchronize()
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    steps = []
+    for n, gi in enumerate(conv_inn):
+        axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+        steps.append({"inn": cpu(gi.state_dict()), "omega": cpu(cond_nets[n].state_dict()), "axes": axes})
+    with torch.no_grad():
+        ref = O.inverse_pass(steps, None, cond_input, mean_cache, lrnn_sd=cpu(enc.state_dict()), lrnn_train=True)[-1]
+    assert out.shape == (1, 96, 512, 512)
+    assert_close(out, ref, TOL, "full-size config-3 inverse")
