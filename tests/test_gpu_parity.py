@@ -629,3 +629,32 @@ def test_full_config3_inverse_vs_oracle():
         ref = O.inverse_pass(steps, None, cond_input, mean_cache, lrnn_sd=cpu(enc.state_dict()), lrnn_train=True)[-1]
     assert out.shape == (1, 96, 512, 512)
     assert_close(out, ref, TOL, "full-size config-3 inverse")
+
+
+def test_full_size_forward_nll_vs_oracle():
+    """BASELINE.json configs[3] per rank: the forward / NLL step of the finest flow (512x512x96 volumes, batch 2) with its
+    condition net, GPU (fused forward chain, float64 shard sums) vs the CPU oracle: latent, low band, log-det, NLL."""
+    from cwfa_amd import CWFA
+    from oracle import cwfa_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, with_lrnn=False, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 96, 512, 512, generator=g)
+    views = torch.randn(2, 29, 512, 512, generator=g)
+    mean = 0.1 * torch.randn(2, 48, 512, 512, generator=g)
+    with torch.no_grad():
+        om = cond_nets[0](views.cuda())[-1]
+        nll, Z, logdet = CWFA.nll_step(conv_inn[0], x.cuda(), [om, mean.cuda()])
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    gi = conv_inn[0]
+    axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+    with torch.no_grad():
+        omr = O.omega_net(cpu(cond_nets[0].state_dict()), views)
+        (zr, lowr), ldr = O.flow_step(cpu(gi.state_dict()), x, [omr, mean], False, axes)
+    assert_close(Z[0], zr, TOL, "latent")
+    assert_close(Z[1], lowr, 2e-6, "low band")
+    assert_close(logdet, ldr, TOL, "log-det")
+    ss, sl, B = O.nll_terms(zr, ldr)
+    ref = O.nll_from_terms(ss, sl, B, lowr.numel())
+    assert abs(float(nll) - ref) <= 1e-5 * abs(ref)
