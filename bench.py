@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--depths", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="(experiment, NOT the headline configuration) 1x1 / transposed convolutions with >= 128 outputs as "
+                         "fp32-accurate split-bf16 GEMMs; the JSON line then says so in `dtype`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,6 +122,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     from cwfa_amd import CWFA, ops
+    if a.split_bf16:
+        ops.set_option("split_bf16", 1)
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN
     torch.manual_seed(0)
     np.random.seed(0)
@@ -176,7 +181,8 @@ def main():
             "metric": "volumes/sec inverse-pass @512x512x96 fp32", "value": world * a.steps * B / elapsed,
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not a.split_bf16 else "f32 (1x1/transposed convs: 3-way split bf16 operands, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA (CAT x5 per scale, 64 ch) + "
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
                                    f"batch {B}/GPU, random-init weights (BASELINE.json configs[2])",

@@ -703,7 +703,286 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
     return CWFA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split-bf16 1x1 GEMM
+// EXPERIMENTAL, opt-in (cwfa_set_option("split_bf16", 1)): 1x1 convolutions / ConvTranspose2d(k2,s2) with >= 128 output
+// channels as an fp32-ACCURATE GEMM on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16
+// pieces (v = v1 + v2 + v3, 24 mantissa bits), the six products with i + j <= 4 are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate / 6 products = 2.7x), error = fp32-level.
+//   * cwfa_split_input_f32: one HBM pass, x (+ load-side affine / added tensor) -> three bf16 planes laid out
+//     [piece][channel group of 8][pixel][8], i.e. exactly the B-operand fragments (16 bytes per lane);
+//   * weights are split at pack time into [cout tile][chunk of 16 ci][piece][k half][256 cout][8];
+//   * the GEMM kernel moves both with LDS-DMA (buffer_load ... lds, no staging registers, two chunks ahead, three LDS
+//     buffers), block = 256 cout x 8 rows x 32 px, 8 waves of 2 x 4 accumulator tiles, the epilogues of the fp32 path.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef Cfg<1, 16, 2, 4, 4, 2> CS;     // 256 ch x 8 rows x 32 cols, 512 threads (geometry only: staging is its own)
+constexpr int CS_XB = 3 * 2 * 8 * 32 * 16, CS_WB = 3 * 2 * 256 * 16, CS_BUFB = CS_XB + CS_WB;    // bytes per LDS buffer
+
+__device__ __forceinline__ void split3(float v, unsigned short (&o)[3]) {
+    const __bf16 a1 = (__bf16)v;
+    const float r1 = v - (float)a1;
+    const __bf16 a2 = (__bf16)r1;
+    const float r2 = r1 - (float)a2;
+    const __bf16 a3 = (__bf16)r2;
+    o[0] = __builtin_bit_cast(unsigned short, a1);
+    o[1] = __builtin_bit_cast(unsigned short, a2);
+    o[2] = __builtin_bit_cast(unsigned short, a3);
+}
+
+// grid (ceil(HW/256), CG2, B): thread = one pixel of one group of 8 channels
+__global__ __launch_bounds__(256) void split_input_kernel(const float* __restrict__ x, uint4* __restrict__ ws, int Cin, int CG2,
+                                                          int64_t HW, int64_t x_bs, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, int64_t aff_bs,
+                                                          const float* __restrict__ add, int64_t add_bs) {
+    const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (px >= HW) return;
+    const int cg = blockIdx.y, b = blockIdx.z;
+    unsigned short pc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        float v = 0.f;
+        if (c < Cin) {
+            v = x[(int64_t)b * x_bs + (int64_t)c * HW + px];
+            if (sc) v = v * sc[(int64_t)b * aff_bs + c] + sh[(int64_t)b * aff_bs + c];
+            if (add) v += add[(int64_t)b * add_bs + (int64_t)c * HW + px];
+        }
+        unsigned short o[3];
+        split3(v, o);
+        pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint4 u;
+        u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
+        u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
+        u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
+        u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
+        ws[(((int64_t)b * 3 + q) * CG2 + cg) * HW + px] = u;
+    }
+}
+
+// one thread per (cout tile, chunk, piece-independent) 8-channel fragment: writes its three pieces
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin,
+                                                         int nchunks, int transposed, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [ctile][chunk][h][co 256]
+    if (i >= total) return;
+    const int col = (int)(i % 256), h = (int)((i / 256) % 2), chunk = (int)((i / 512) % nchunks);
+    const int ctile = (int)(i / ((int64_t)512 * nchunks));
+    const int co = ctile * 256 + col;
+    unsigned short pc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = chunk * 16 + h * 8 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = transposed ? w[((int64_t)ci * (Cout / 4) + (co >> 2)) * 4 + (co & 3)] : w[(int64_t)co * Cin + ci];
+        unsigned short o[3];
+        split3(v, o);
+        pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint4 u;
+        u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
+        u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
+        u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
+        u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
+        out[(((int64_t)ctile * nchunks + chunk) * 3 + q) * 512 + h * 256 + col] = u;
+    }
+}
+
+struct SplitParams {
+    ConvParams c;           // x unused; wp = split weights; the epilogue fields as in the fp32 path
+    const void* ws;         // split input planes
+    int CG2;
+    int64_t ws_bs;          // bytes per sample
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
+    typedef CS C;
+    const ConvParams& p = sp.c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const Tile t = make_tile<C>(p);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t HW = (int64_t)p.H * p.W;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // LDS-DMA: entry e = tid + i*512 of a buffer part (16 bytes each); a wave instruction fills 1 KB contiguously
+    unsigned xoff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = tid + i * 512;
+        const int px = e & 31, row = (e >> 5) & 7, h = (e >> 8) & 1, piece = e >> 9;
+        const int gr = t.row0 + row, gc = t.col0 + px;
+        xoff[i] = (gr < p.H && gc < p.W) ? (unsigned)((((int64_t)piece * sp.CG2 + h) * HW + (int64_t)gr * p.W + gc) * 16) : OOB;
+    }
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sp.ws) + (int64_t)t.b * sp.ws_bs),
+                                                      0, (int)sp.ws_bs, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.wp) + (int64_t)t.ct * p.nchunks * CS_WB), 0, p.nchunks * CS_WB, 0x00020000);
+    const int xchunk = (int)(2 * HW * 16);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto dma = [&](int chunk, int buf) {          // chunks past the end: out of range, zeros, never read
+        char* base = lds + buf * CS_BUFB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(base + i * 8192), 16, xoff[i], chunk * xchunk, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + CS_XB + i * 8192), 16, (unsigned)(tid + i * 512) * 16u,
+                                                     chunk * CS_WB, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const char* alane = lds + CS_XB + ((t.kh * 256) + t.wm * 64 + t.l31) * 16;        // + (piece*512 + m*32) * 16
+    const char* blane = lds + ((t.kh * 8 + t.wn * 4) * 32 + t.l31) * 16;               // + (piece*512 + n*32) * 16
+
+    dma(0, 0);
+    dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        int nb = buf + 2;
+        nb = nb >= 3 ? nb - 3 : nb;
+        dma(chunk + 2, nb);
+        const char* ab = alane + buf * CS_BUFB;
+        const char* bb = blane + buf * CS_BUFB;
+        bf16x8 A[2][3], Bq[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 512 + m * 32) * 16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Bq[0][q] = *reinterpret_cast<const bf16x8*>(bb + (q * 512) * 16);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (n < 3) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Bq[(n + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(bb + (q * 512 + (n + 1) * 32) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                // smallest terms first: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
+                f32x16 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][2], Bq[n & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][0], c, 0, 0, 0);
+                acc[m][n] = c;
+            }
+        }
+        // the DMA of chunk + 1 (issued one chunk ago) must have landed everywhere; the six just issued may stay in flight
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = buf + 1 == 3 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the zero-fill DMAs before LDS is reused / the block ends
+    __syncthreads();
+    epilogue<C, EPI>(p, t, acc);
+}
+
+template <int EPI>
+int launch_split(SplitParams sp, hipStream_t stream) {
+    dim3 grid;
+    ConvParams& p = sp.c;
+    p.tiles_x = (p.W + CS::TC - 1) / CS::TC;
+    p.tiles_y = (p.H + CS::TR - 1) / CS::TR;
+    const int ctiles = (p.Cout + CS::CT - 1) / CS::CT;
+    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
+                 "cwfa_conv1x1_split_f32: grid too large");
+    constexpr int LDS = 3 * CS_BUFB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            cwfa_set_error("cwfa_conv1x1_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
+            return CWFA_E_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv1x1_split_kernel<EPI>), dim3((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B), dim3(512), LDS, stream, sp);
+    CWFA_LAUNCH_CHECK("cwfa_conv1x1_split_f32");
+    return CWFA_OK;
+}
+
 }  // namespace
+
+extern "C" int64_t cwfa_split_workspace_bytes(int B, int Cin, int64_t HW) {
+    if (B < 0 || Cin <= 0 || HW < 0) return -1;
+    const int64_t CG2 = 2 * ((Cin + 15) / 16);
+    return (int64_t)B * 3 * CG2 * HW * 16;
+}
+
+extern "C" int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, int64_t HW, int64_t x_bs, const float* in_scale,
+                                    const float* in_shift, int64_t in_affine_bs, const float* in_add, int64_t in_add_bs,
+                                    void* stream) {
+    CWFA_REQUIRE(x && ws, CWFA_E_INVAL, "cwfa_split_input_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && Cin > 0 && HW >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_split_input_f32: bad shape");
+    CWFA_REQUIRE(!in_scale == !in_shift, CWFA_E_INVAL, "cwfa_split_input_f32: in_scale and in_shift go together");
+    CWFA_REQUIRE(cwfa_aligned16(ws), CWFA_E_ALIGN, "cwfa_split_input_f32: workspace must be 16-byte aligned");
+    if (B == 0 || HW == 0) return CWFA_OK;
+    const int CG2 = 2 * ((Cin + 15) / 16);
+    CWFA_REQUIRE((int64_t)3 * CG2 * HW * 16 < (1ll << 31), CWFA_E_SHAPE, "cwfa_split_input_f32: one sample's planes must stay below 2 GiB");
+    hipLaunchKernelGGL(split_input_kernel, dim3((unsigned)((HW + 255) / 256), CG2, B), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<uint4*>(ws), Cin, CG2, HW, x_bs, in_scale, in_shift, in_affine_bs, in_add, in_add_bs);
+    CWFA_LAUNCH_CHECK("cwfa_split_input_f32");
+    return CWFA_OK;
+}
+
+extern "C" int64_t cwfa_conv1x1_split_packed_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return -1;
+    return (int64_t)((Cout + 255) / 256) * ((Cin + 15) / 16) * CS_WB;
+}
+
+extern "C" int cwfa_conv1x1_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int transposed, void* stream) {
+    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv1x1_split_pack_f32: null pointer");
+    CWFA_REQUIRE(Cout > 0 && Cin > 0 && (!transposed || Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv1x1_split_pack_f32: bad shape");
+    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv1x1_split_pack_f32: packed image must be 16-byte aligned");
+    const int nchunks = (Cin + 15) / 16;
+    const int64_t total = (int64_t)((Cout + 255) / 256) * nchunks * 512;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<uint4*>(packed), Cout, Cin, nchunks, transposed, total);
+    CWFA_LAUNCH_CHECK("cwfa_conv1x1_split_pack_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_conv1x1_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                                      int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv1x1_split_f32: null pointer");
+    SplitParams sp{};
+    int rc = fill_params(sp.c, "cwfa_conv1x1_split_f32", reinterpret_cast<const float*>(ws), reinterpret_cast<const float*>(w_packed), y,
+                         B, Cin, H, W, Cout, 0, y_bs, opts);
+    if (rc) return rc < 0 ? rc : CWFA_OK;
+    ConvParams& p = sp.c;
+    CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add, CWFA_E_INVAL, "cwfa_conv1x1_split_f32: the load-side prologue belongs in cwfa_split_input_f32");
+    CWFA_REQUIRE(!p.o.upshuffle2 || Cout % 4 == 0, CWFA_E_SHAPE, "cwfa_conv1x1_split_f32: upshuffle2 needs Cout = 4*Co");
+    p.nchunks = (Cin + 15) / 16;
+    sp.ws = ws;
+    sp.CG2 = 2 * p.nchunks;
+    sp.ws_bs = (int64_t)3 * sp.CG2 * H * W * 16;
+    CWFA_REQUIRE(sp.ws_bs + (int64_t)4 * H * W * 16 < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv1x1_split_f32: one sample's planes must stay below 2 GiB");
+    const int epi = classify_epilogue(p.o);
+    hipStream_t st = (hipStream_t)stream;
+    switch (epi) {
+        case EPI_NONE: return launch_split<EPI_NONE>(sp, st);
+        case EPI_UP: return launch_split<EPI_UP>(sp, st);
+        default: return launch_split<EPI_GENERIC>(sp, st);
+    }
+}
+
+
 
 int g_cwfa_wino_min_cout = 1;
 int g_cwfa_wino_2d = 0;

@@ -218,11 +218,12 @@ def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
-    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr")
+    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split")
 
-    def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr):
+    def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
         self.transposed, self.version, self.src_ptr = transposed, version, src_ptr
+        self.split = split          # weights held as three bf16 pieces for the split-bf16 GEMM (opt-in, see set_option)
 
 
 def pack_conv_weight(w, transposed=False):
@@ -238,6 +239,10 @@ def pack_conv_weight(w, transposed=False):
         cout, cin, ks, kw = w.shape
         if ks != kw:
             raise ValueError("square kernels only")
+    if _split_bf16 and ks == 1 and cout >= 128:
+        packed = torch.empty(L.cwfa_conv1x1_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+        check(L.cwfa_conv1x1_split_pack_f32(_p(w), _p(packed), cout, cin, int(transposed), _stream()), "conv1x1_split_pack")
+        return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
     n = L.cwfa_conv2d_packed_floats(cout, cin, ks)
     if n <= 0:
         raise ValueError(f"unsupported filter bank {tuple(w.shape)}")
@@ -302,8 +307,18 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-    check(L.cwfa_conv2d_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, pc.ks, xbs, ybs, C.byref(o),
-                            _stream()), "conv2d")
+    if pc.split:
+        # fp32-accurate GEMM on the bf16 pipe: one pass splits x (with the load-side prologue) into three bf16 planes
+        ws = torch.empty(L.cwfa_split_workspace_bytes(B, Cin, H * W), dtype=torch.uint8, device=x.device)
+        per_sample = in_scale is not None and in_scale.numel() == B * Cin and B > 1
+        check(L.cwfa_split_input_f32(_p(x), _p(ws), B, Cin, H * W, xbs, _p(in_scale), _p(in_shift), Cin if per_sample else 0,
+                                     _p(in_add), in_add.stride(0) if in_add is not None else 0, _stream()), "split_input")
+        o.in_scale = o.in_shift = o.in_add = None
+        check(L.cwfa_conv1x1_split_f32(_p(ws), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, ybs, C.byref(o), _stream()),
+              "conv1x1_split")
+    else:
+        check(L.cwfa_conv2d_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, pc.ks, xbs, ybs, C.byref(o),
+                                _stream()), "conv2d")
     if rec is not None and rec.want(key):
         e1.record()
         rec.add(key, e0, e1)
@@ -477,9 +492,18 @@ def extract_views(image, coords_yx, subimage_shape, mean=0.0, std=1.0):
     return out
 
 
+_split_bf16 = False
+
+
 def set_option(name, value):
-    """Process-wide tuning option of the library (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed
-    before a change of "winograd_min_cout" must be re-packed."""
+    """Process-wide tuning option (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed before a change of
+    "winograd_min_cout" / "winograd_2d" / "split_bf16" must be re-packed.
+    "split_bf16" (host-side switch, default 0): 1x1 convolutions and ConvTranspose2d(k2,s2) with >= 128 output channels
+    run as an fp32-accurate GEMM on the bf16 matrix pipe (cwfa_split_input_f32 + cwfa_conv1x1_split_f32)."""
+    global _split_bf16
+    if name == "split_bf16":
+        _split_bf16 = bool(value)
+        return
     check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")
 
 

@@ -658,3 +658,52 @@ def test_full_size_forward_nll_vs_oracle():
     ss, sl, B = O.nll_terms(zr, ldr)
     ref = O.nll_from_terms(ss, sl, B, lowr.numel())
     assert abs(float(nll) - ref) <= 1e-5 * abs(ref)
+
+
+@pytest.mark.parametrize("cfg", [(1, 70, 16, 32, 200), (2, 33, 9, 37, 130), (1, 256, 24, 64, 512)])
+def test_split_bf16_1x1_is_fp32_accurate(cfg):
+    """Opt-in split-bf16 GEMM (three bf16 pieces per operand, six products, fp32 accumulate): same tolerance as the fp32
+    matrix-core path against an fp64 reference, with prologue, epilogues and ragged tiles."""
+    from cwfa_amd import ops
+    B, Cin, H, W, Cout = cfg
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    alpha = torch.tensor([0.2])
+    sc, sh = torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    xin = x.double() * sc.double().view(B, -1, 1, 1) + sh.double().view(B, -1, 1, 1) + add.double()
+    ref_pro = F.prelu(F.conv2d(xin, w.double(), b.double()), alpha.double())
+    ops.set_option("split_bf16", 1)
+    try:
+        pc = ops.pack_conv_weight(w.cuda())
+        assert pc.split
+        y = ops.conv2d(x.cuda(), pc, bias=b.cuda())
+        y2 = ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="elu", residual=res.cuda(), act2="elu")
+        y3 = ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                        in_add=add.cuda())
+    finally:
+        ops.set_option("split_bf16", 0)
+    assert_close(y, ref, 2e-6, "plain")
+    assert_close(y2, F.elu(F.elu(ref) + res.double()), 3e-6, "elu+res+elu")
+    assert_close(y3, ref_pro, 3e-6, "prologue + prelu")
+
+
+def test_split_bf16_conv_transpose():
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 40, 9, 16, generator=g)
+    w = torch.randn(40, 48, 2, 2, generator=g) * 0.2
+    b = torch.randn(48, generator=g)
+    ops.set_option("split_bf16", 1)
+    try:
+        pc = ops.pack_conv_weight(w.cuda(), transposed=True)
+        assert pc.split
+        y = ops.conv2d(x.cuda(), pc, bias=b.cuda())
+    finally:
+        ops.set_option("split_bf16", 0)
+    assert_close(y, torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2), 2e-6)
