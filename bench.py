@@ -97,9 +97,11 @@ def main():
     ap.add_argument("--depths", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="(experiment, NOT the headline configuration) 1x1 / transposed convolutions with >= 128 outputs as "
-                         "fp32-accurate split-bf16 GEMMs; the JSON line then says so in `dtype`")
+    ap.add_argument("--no-experiment", action="store_true", help="skip the extra split-bf16 measurement after the timed region")
+    ap.add_argument("--split-bf16", type=int, default=0, choices=(0, 1, 2),
+                    help="(experiment, NOT the headline configuration) fp32-accurate split-bf16 matrix-core kernels: 1 = 1x1 / "
+                         "transposed convolutions with >= 128 outputs, 2 = also the 3x3 convolutions with >= 192 outputs; the "
+                         "JSON line then says so in `dtype`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +125,7 @@ def main():
 
     from cwfa_amd import CWFA, ops
     if a.split_bf16:
-        ops.set_option("split_bf16", 1)
+        ops.set_option("split_bf16", a.split_bf16)
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN
     torch.manual_seed(0)
     np.random.seed(0)
@@ -181,7 +183,7 @@ def main():
             "metric": "volumes/sec inverse-pass @512x512x96 fp32", "value": world * a.steps * B / elapsed,
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not a.split_bf16 else "f32 (1x1/transposed convs: 3-way split bf16 operands, fp32 accumulate)",
+            "dtype": "f32" if not a.split_bf16 else f"f32 (split level {a.split_bf16}: 3-way split bf16 operands, six products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA (CAT x5 per scale, 64 ch) + "
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
@@ -205,6 +207,8 @@ def main():
         }
         res["roofline"]["traffic"], res["roofline"]["traffic_detail"] = pmc_traffic(dom, a)
         res["roofline_dwt"] = dwt_roofline(ops, a, dev)
+        if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
+            res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3))
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
             res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
         print(json.dumps(res), flush=True)
@@ -212,6 +216,26 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def split_experiment(ops, step, steps):
+    """NOT the headline: the same step with the opt-in fp32-accurate split-bf16 matrix-core kernels (level 2: 1x1 /
+    transposed convs and the 3x3 convs with >= 192 outputs), measured after the timed region, for the record."""
+    ops.set_option("split_bf16", 2)
+    try:
+        step(); step()                                       # re-pack the affected filter banks, warm up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        ops.set_option("split_bf16", 0)
+    return {"value": 1.0 / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps,
+            "note": "opt-in, not the headline configuration: operands split exactly into three bf16 pieces, six partial "
+                    "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; parity tests hold the fp32 path's bounds "
+                    "(tests/test_gpu_parity.py::test_split_bf16_*)"}
 
 
 def pmc_traffic(dom, a):

@@ -68,7 +68,7 @@ class Fixed1x1Conv(InvertibleModule):
     def _bank(self, rev):
         w = self.M_inv if rev else self.M
         pc = self._packed.get(rev)
-        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr():
+        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch():
             pc = self._packed[rev] = ops.pack_conv_weight(w)
         return pc
 

@@ -65,9 +65,9 @@ SIGNATURES = {
     "cwfa_bn_running_update_f32": (i, [p, C.c_double, f, p, p, p, i, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),
-    "cwfa_conv1x1_split_packed_bytes": (i64, [i, i]),
-    "cwfa_conv1x1_split_pack_f32": (i, [p, p, i, i, i, p]),
-    "cwfa_conv1x1_split_f32": (i, [p, p, p, i, i, i, i, i, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),
+    "cwfa_conv_split_pack_f32": (i, [p, p, i, i, i, i, p]),
+    "cwfa_conv_split_f32": (i, [p, p, p, i, i, i, i, i, i, i64, C.POINTER(ConvOpts), p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

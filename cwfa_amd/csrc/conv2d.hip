@@ -761,20 +761,22 @@ __global__ __launch_bounds__(256) void split_input_kernel(const float* __restric
     }
 }
 
-// one thread per (cout tile, chunk, piece-independent) 8-channel fragment: writes its three pieces
+// one thread per (cout tile, chunk, tap, k half, cout) 8-channel fragment: writes its three pieces
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin,
-                                                         int nchunks, int transposed, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [ctile][chunk][h][co 256]
+                                                         int nchunks, int taps, int transposed, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [ctile][chunk][tap][h][co 256]
     if (i >= total) return;
-    const int col = (int)(i % 256), h = (int)((i / 256) % 2), chunk = (int)((i / 512) % nchunks);
-    const int ctile = (int)(i / ((int64_t)512 * nchunks));
+    const int col = (int)(i % 256), h = (int)((i / 256) % 2), tap = (int)((i / 512) % taps);
+    const int chunk = (int)((i / (512 * (int64_t)taps)) % nchunks);
+    const int ctile = (int)(i / ((int64_t)512 * taps * nchunks));
     const int co = ctile * 256 + col;
     unsigned short pc[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = chunk * 16 + h * 8 + j;
         float v = 0.f;
-        if (co < Cout && ci < Cin) v = transposed ? w[((int64_t)ci * (Cout / 4) + (co >> 2)) * 4 + (co & 3)] : w[(int64_t)co * Cin + ci];
+        if (co < Cout && ci < Cin)
+            v = transposed ? w[((int64_t)ci * (Cout / 4) + (co >> 2)) * 4 + (co & 3)] : w[((int64_t)co * Cin + ci) * taps + tap];
         unsigned short o[3];
         split3(v, o);
         pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
         u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
         u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
         u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
-        out[(((int64_t)ctile * nchunks + chunk) * 3 + q) * 512 + h * 256 + col] = u;
+        out[((((int64_t)ctile * nchunks + chunk) * taps + tap) * 3 + q) * 512 + h * 256 + col] = u;
     }
 }
 
@@ -892,7 +894,149 @@ __global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
     epilogue<C, EPI>(p, t, acc);
 }
 
+// 3x3: the same GEMM core with a nine-tap inner loop.  The haloed input tile of a 16-channel chunk
+// [piece][k half][10 rows][34 px] x 16 B stays in LDS for all nine taps (two buffers, DMA'd one chunk ahead; zero padding
+// and channels >= Cin come out of the buffer range check), a tap only shifts the B-operand address by a constant; the
+// weights arrive one 24.6 KB slice per tap-step through a three-buffer ring, two steps ahead.
+constexpr int CS3_XE = 3 * 2 * 10 * 34, CS3_XB = 2048 * 16;      // entries used / bytes reserved per input buffer (4 DMA items per thread)
+
 template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
+    typedef CS C;
+    const ConvParams& p = sp.c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);                   // [2 x CS3_XB input][3 x CS_WB weights]
+    const Tile t = make_tile<C>(p);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t HW = (int64_t)p.H * p.W;
+    constexpr unsigned OOB = 0x80000000u;
+
+    unsigned xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 512;
+        const int c = e % 34, r = (e / 34) % 10, h = (e / 340) % 2, piece = e / 680;
+        const int gr = t.row0 + r - 1, gc = t.col0 + c - 1;
+        const bool ok = e < CS3_XE && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
+        xoff[i] = ok ? (unsigned)((((int64_t)piece * sp.CG2 + h) * HW + (int64_t)gr * p.W + gc) * 16) : OOB;
+    }
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sp.ws) + (int64_t)t.b * sp.ws_bs),
+                                                      0, (int)sp.ws_bs, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.wp) + (int64_t)t.ct * p.nchunks * 9 * CS_WB), 0, p.nchunks * 9 * CS_WB,
+        0x00020000);
+    const int xchunk = (int)(2 * HW * 16);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto dma_w = [&](int step, int wbuf) {        // steps past the end: out of range, zeros, never read
+        char* base = lds + 2 * CS3_XB + wbuf * CS_WB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + i * 8192), 16, (unsigned)(tid + i * 512) * 16u, step * CS_WB, 0, 0);
+    };
+    auto dma_x = [&](int i, int chunk, int xbuf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(lds + xbuf * CS3_XB + wave * 1024 + i * 8192), 16, xoff[i],
+                                                 chunk * xchunk, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const char* alane = lds + 2 * CS3_XB + ((t.kh * 256) + t.wm * 64 + t.l31) * 16;          // + wbuf*CS_WB + (piece*512 + m*32)*16
+    const char* blane = lds + ((t.kh * 10 + t.wn * 4) * 34 + t.l31) * 16;                     // + xbuf*CS3_XB + (piece*680 + (n+dy)*34 + dx)*16
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_x(i, 0, 0);
+    dma_w(0, 0);
+    dma_w(1, 1);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // Operand registers: two A sets (the set of step t+1 is read in the second half of step t, AFTER the mid-step barrier
+    // that makes weight slice t+1 visible), B ring of two (the first B fragment of step t+1 is read during the last
+    // n-tile of step t: the input tile is complete long before).  Without this both waves of a SIMD sat through one LDS
+    // round trip after every barrier.
+    bf16x8 A[2][2][3], Bq[2][3];
+    auto load_a = [&](auto setc, int wb) {
+        constexpr int set = decltype(setc)::value;
+        const char* ab = alane + wb * CS_WB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[set][m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 512 + m * 32) * 16);
+    };
+    load_a(sc_int<0>{}, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Bq[0][q] = *reinterpret_cast<const bf16x8*>(blane + (q * 680) * 16);
+    int wbuf = 0, step = 0;
+    auto chunk_body = [&](auto parc, int chunk) {
+        constexpr int par = decltype(parc)::value;
+        const char* xb = blane + (chunk & 1) * CS3_XB;
+        const char* xn = blane + ((chunk + 1) & 1) * CS3_XB;
+        static_for<9>([&](auto tc) {
+            constexpr int tap = decltype(tc)::value, dy = tap / 3, dx = tap % 3, set = (par + tap) & 1;
+            constexpr int ntap = (tap + 1) % 9, ndy = ntap / 3, ndx = ntap % 3;
+            int nb = wbuf + 2;
+            nb = nb >= 3 ? nb - 3 : nb;
+#ifndef CWFA_EXP_SPLIT_NODMA
+            dma_w(step + 2, nb);
+            if constexpr (tap < 4) dma_x(tap, chunk + 1, (chunk + 1) & 1);      // next chunk's input tile, one item per step
+#endif
+            int w1 = wbuf + 1;
+            w1 = w1 == 3 ? 0 : w1;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n < 3) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        Bq[(n + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(xb + (q * 680 + (n + 1 + dy) * 34 + dx) * 16);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        Bq[0][q] = *reinterpret_cast<const bf16x8*>((tap == 8 ? xn : xb) + (q * 680 + ndy * 34 + ndx) * 16);
+                }
+                if (n == 2) {
+                    // weight slice step+1 (issued one step ago) has landed everywhere; this step's own DMAs may stay in flight
+#ifndef CWFA_EXP_SPLIT_NODMA
+                    if constexpr (tap < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef CWFA_EXP_SPLIT_NOBAR
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    load_a(sc_int<set ^ 1>{}, w1);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x16 c = acc[m][n];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][2], Bq[n & 1][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][0], c, 0, 0, 0);
+                    acc[m][n] = c;
+                }
+            }
+            wbuf = w1;
+            ++step;
+        });
+    };
+    int chunk = 0;
+    for (; chunk + 1 < p.nchunks; chunk += 2) {
+        chunk_body(sc_int<0>{}, chunk);
+        chunk_body(sc_int<1>{}, chunk + 1);
+    }
+    if (chunk < p.nchunks) chunk_body(sc_int<0>{}, chunk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    epilogue<C, EPI>(p, t, acc);
+}
+
+template <int EPI, int KS>
 int launch_split(SplitParams sp, hipStream_t stream) {
     dim3 grid;
     ConvParams& p = sp.c;
@@ -901,19 +1045,19 @@ int launch_split(SplitParams sp, hipStream_t stream) {
     const int ctiles = (p.Cout + CS::CT - 1) / CS::CT;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
                  "cwfa_conv1x1_split_f32: grid too large");
-    constexpr int LDS = 3 * CS_BUFB;
+    constexpr int LDS = KS == 1 ? 3 * CS_BUFB : 2 * CS3_XB + 3 * CS_WB;
+    auto kern = KS == 1 ? &conv1x1_split_kernel<EPI> : &conv3x3_split_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             cwfa_set_error("cwfa_conv1x1_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
             return CWFA_E_HIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv1x1_split_kernel<EPI>), dim3((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B), dim3(512), LDS, stream, sp);
-    CWFA_LAUNCH_CHECK("cwfa_conv1x1_split_f32");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * p.tiles_y), ctiles, p.B), dim3(512), LDS, stream, sp);
+    CWFA_LAUNCH_CHECK("cwfa_conv_split_f32");
     return CWFA_OK;
 }
 
@@ -941,48 +1085,56 @@ extern "C" int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, in
     return CWFA_OK;
 }
 
-extern "C" int64_t cwfa_conv1x1_split_packed_bytes(int Cout, int Cin) {
-    if (Cout <= 0 || Cin <= 0) return -1;
-    return (int64_t)((Cout + 255) / 256) * ((Cin + 15) / 16) * CS_WB;
+extern "C" int64_t cwfa_conv_split_packed_bytes(int Cout, int Cin, int ks) {
+    if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return -1;
+    return (int64_t)((Cout + 255) / 256) * ((Cin + 15) / 16) * ks * ks * CS_WB;
 }
 
-extern "C" int cwfa_conv1x1_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int transposed, void* stream) {
-    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv1x1_split_pack_f32: null pointer");
-    CWFA_REQUIRE(Cout > 0 && Cin > 0 && (!transposed || Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv1x1_split_pack_f32: bad shape");
-    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv1x1_split_pack_f32: packed image must be 16-byte aligned");
-    const int nchunks = (Cin + 15) / 16;
-    const int64_t total = (int64_t)((Cout + 255) / 256) * nchunks * 512;
+extern "C" int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int ks, int transposed, void* stream) {
+    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv_split_pack_f32: null pointer");
+    CWFA_REQUIRE(Cout > 0 && Cin > 0 && (ks == 1 || ks == 3) && (!transposed || (ks == 1 && Cout % 4 == 0)), CWFA_E_SHAPE,
+                 "cwfa_conv_split_pack_f32: bad shape");
+    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv_split_pack_f32: packed image must be 16-byte aligned");
+    const int nchunks = (Cin + 15) / 16, taps = ks * ks;
+    const int64_t total = (int64_t)((Cout + 255) / 256) * nchunks * taps * 512;
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<uint4*>(packed), Cout, Cin, nchunks, transposed, total);
-    CWFA_LAUNCH_CHECK("cwfa_conv1x1_split_pack_f32");
+                       reinterpret_cast<uint4*>(packed), Cout, Cin, nchunks, taps, transposed, total);
+    CWFA_LAUNCH_CHECK("cwfa_conv_split_pack_f32");
     return CWFA_OK;
 }
 
-extern "C" int cwfa_conv1x1_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
-                                      int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
-    CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv1x1_split_f32: null pointer");
+extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
+                                   int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv_split_f32: null pointer");
+    CWFA_REQUIRE(ks == 1 || ks == 3, CWFA_E_SHAPE, "cwfa_conv_split_f32: kernel size %d not in {1,3}", ks);
     SplitParams sp{};
-    int rc = fill_params(sp.c, "cwfa_conv1x1_split_f32", reinterpret_cast<const float*>(ws), reinterpret_cast<const float*>(w_packed), y,
+    int rc = fill_params(sp.c, "cwfa_conv_split_f32", reinterpret_cast<const float*>(ws), reinterpret_cast<const float*>(w_packed), y,
                          B, Cin, H, W, Cout, 0, y_bs, opts);
     if (rc) return rc < 0 ? rc : CWFA_OK;
     ConvParams& p = sp.c;
-    CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add, CWFA_E_INVAL, "cwfa_conv1x1_split_f32: the load-side prologue belongs in cwfa_split_input_f32");
-    CWFA_REQUIRE(!p.o.upshuffle2 || Cout % 4 == 0, CWFA_E_SHAPE, "cwfa_conv1x1_split_f32: upshuffle2 needs Cout = 4*Co");
+    CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add, CWFA_E_INVAL, "cwfa_conv_split_f32: the load-side prologue belongs in cwfa_split_input_f32");
+    CWFA_REQUIRE(!p.o.upshuffle2 || (ks == 1 && Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv_split_f32: upshuffle2 needs ks=1, Cout=4*Co");
     p.nchunks = (Cin + 15) / 16;
     sp.ws = ws;
     sp.CG2 = 2 * p.nchunks;
     sp.ws_bs = (int64_t)3 * sp.CG2 * H * W * 16;
-    CWFA_REQUIRE(sp.ws_bs + (int64_t)4 * H * W * 16 < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv1x1_split_f32: one sample's planes must stay below 2 GiB");
+    CWFA_REQUIRE(sp.ws_bs + (int64_t)4 * H * W * 16 < (1ll << 31) && (int64_t)(p.nchunks * ks * ks + 2) * CS_WB < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv_split_f32: one sample's planes / one cout tile's weights must stay below 2 GiB");
     const int epi = classify_epilogue(p.o);
     hipStream_t st = (hipStream_t)stream;
+    if (ks == 1) {
+        switch (epi) {
+            case EPI_NONE: return launch_split<EPI_NONE, 1>(sp, st);
+            case EPI_UP: return launch_split<EPI_UP, 1>(sp, st);
+            default: return launch_split<EPI_GENERIC, 1>(sp, st);
+        }
+    }
     switch (epi) {
-        case EPI_NONE: return launch_split<EPI_NONE>(sp, st);
-        case EPI_UP: return launch_split<EPI_UP>(sp, st);
-        default: return launch_split<EPI_GENERIC>(sp, st);
+        case EPI_NONE: return launch_split<EPI_NONE, 3>(sp, st);
+        case EPI_PRELU: return launch_split<EPI_PRELU, 3>(sp, st);
+        default: return launch_split<EPI_GENERIC, 3>(sp, st);
     }
 }
-
-
 
 int g_cwfa_wino_min_cout = 1;
 int g_cwfa_wino_2d = 0;

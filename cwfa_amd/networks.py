@@ -144,7 +144,7 @@ class wavelet_flow_subnetwork(nn.Module):
     def _panel(self, conv):
         w = conv.weight
         pc = self._panels.get(id(conv))
-        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr():
+        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch():
             pc = self._panels[id(conv)] = ops.pack_1x1_panel(w)
         return pc
 

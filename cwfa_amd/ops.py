@@ -218,12 +218,13 @@ def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
-    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split")
+    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch")
 
     def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
         self.transposed, self.version, self.src_ptr = transposed, version, src_ptr
         self.split = split          # weights held as three bf16 pieces for the split-bf16 GEMM (opt-in, see set_option)
+        self.epoch = _pack_epoch    # set_option() generation this image was built under (caches re-pack on a change)
 
 
 def pack_conv_weight(w, transposed=False):
@@ -239,9 +240,9 @@ def pack_conv_weight(w, transposed=False):
         cout, cin, ks, kw = w.shape
         if ks != kw:
             raise ValueError("square kernels only")
-    if _split_bf16 and ks == 1 and cout >= 128:
-        packed = torch.empty(L.cwfa_conv1x1_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
-        check(L.cwfa_conv1x1_split_pack_f32(_p(w), _p(packed), cout, cin, int(transposed), _stream()), "conv1x1_split_pack")
+    if (_split_bf16 and ks == 1 and cout >= 128) or (_split_bf16 >= 2 and ks == 3 and cout >= 192):
+        packed = torch.empty(L.cwfa_conv_split_packed_bytes(cout, cin, ks), dtype=torch.uint8, device=w.device)
+        check(L.cwfa_conv_split_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
     n = L.cwfa_conv2d_packed_floats(cout, cin, ks)
     if n <= 0:
@@ -314,8 +315,8 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         check(L.cwfa_split_input_f32(_p(x), _p(ws), B, Cin, H * W, xbs, _p(in_scale), _p(in_shift), Cin if per_sample else 0,
                                      _p(in_add), in_add.stride(0) if in_add is not None else 0, _stream()), "split_input")
         o.in_scale = o.in_shift = o.in_add = None
-        check(L.cwfa_conv1x1_split_f32(_p(ws), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, ybs, C.byref(o), _stream()),
-              "conv1x1_split")
+        check(L.cwfa_conv_split_f32(_p(ws), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, pc.ks, ybs, C.byref(o), _stream()),
+              "conv_split")
     else:
         check(L.cwfa_conv2d_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, pc.ks, xbs, ybs, C.byref(o),
                                 _stream()), "conv2d")
@@ -492,17 +493,24 @@ def extract_views(image, coords_yx, subimage_shape, mean=0.0, std=1.0):
     return out
 
 
-_split_bf16 = False
+_split_bf16 = 0
+_pack_epoch = 0
+
+
+def pack_epoch():
+    """Generation counter of the packing-relevant options; a cached PackedConv with another epoch must be rebuilt."""
+    return _pack_epoch
 
 
 def set_option(name, value):
     """Process-wide tuning option (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed before a change of
     "winograd_min_cout" / "winograd_2d" / "split_bf16" must be re-packed.
     "split_bf16" (host-side switch, default 0): 1x1 convolutions and ConvTranspose2d(k2,s2) with >= 128 output channels
-    run as an fp32-accurate GEMM on the bf16 matrix pipe (cwfa_split_input_f32 + cwfa_conv1x1_split_f32)."""
-    global _split_bf16
-    if name == "split_bf16":
-        _split_bf16 = bool(value)
+    run as an fp32-accurate GEMM on the bf16 matrix pipe (cwfa_split_input_f32 + cwfa_conv_split_f32)."""
+    global _split_bf16, _pack_epoch
+    _pack_epoch += 1
+    if name == "split_bf16":          # 0 off, 1: 1x1 / transposed convs, 2: also 3x3 convs with >= 192 output channels
+        _split_bf16 = int(value)
         return
     check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")
 

@@ -31,7 +31,7 @@ class _Packed:
     def get(self, conv, transposed=False):
         w = conv.weight
         pc = self._c.get(id(conv))
-        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr():
+        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch():
             pc = self._c[id(conv)] = ops.pack_conv_weight(w, transposed=transposed)
         return pc
 

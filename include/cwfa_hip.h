@@ -239,19 +239,19 @@ int cwfa_scale_channels_f32(const float* x, const float* scale_bc, float* y, int
 int cwfa_axpby_f32(const float* x, const float* z, float a, float b, float* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * EXPERIMENTAL: fp32-accurate 1x1 convolution / ConvTranspose2d(k2,s2) on the bf16 matrix pipe (same reference ops as
- * cwfa_conv2d_f32 with ks = 1: nn.Conv2d 1x1 networks.py:488-492, nn.ConvTranspose2d unet.py:166).  Each fp32 operand is
+ * EXPERIMENTAL: fp32-accurate 1x1 / 3x3 convolution and ConvTranspose2d(k2,s2) on the bf16 matrix pipe (same reference ops
+ * as cwfa_conv2d_f32 with ks = 1 or 3, tiles of 256 output channels: nn.Conv2d 1x1 networks.py:488-492, nn.ConvTranspose2d unet.py:166).  Each fp32 operand is
  * split exactly into three bf16 pieces, six partial products are accumulated in fp32.
  *   cwfa_split_workspace_bytes / cwfa_split_input_f32 : x [B,Cin,HW] (+ per-channel or per-(sample,channel) affine,
  *       + added tensor, as cwfa_conv_opts in_*) -> three bf16 planes in `ws` (16-byte aligned);
- *   cwfa_conv1x1_split_packed_bytes / _pack_f32 : torch weight [Cout,Cin] (or ConvTranspose2d [Cin,Co,2,2]) -> split image;
- *   cwfa_conv1x1_split_f32 : y = epilogue(W . x) with bias / act / residual / act2 / upshuffle2 of `opts` (in_* must be null). */
+ *   cwfa_conv_split_packed_bytes / _pack_f32 : torch weight [Cout,Cin] (or ConvTranspose2d [Cin,Co,2,2]) -> split image;
+ *   cwfa_conv_split_f32 : y = epilogue(W . x) with bias / act / residual / act2 / upshuffle2 of `opts` (in_* must be null). */
 int64_t cwfa_split_workspace_bytes(int B, int Cin, int64_t HW);
 int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, int64_t HW, int64_t x_bs, const float* in_scale,
                          const float* in_shift, int64_t in_affine_bs, const float* in_add, int64_t in_add_bs, void* stream);
-int64_t cwfa_conv1x1_split_packed_bytes(int Cout, int Cin);
-int cwfa_conv1x1_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int transposed, void* stream);
-int cwfa_conv1x1_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t y_bs,
+int64_t cwfa_conv_split_packed_bytes(int Cout, int Cin, int ks);
+int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int ks, int transposed, void* stream);
+int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -707,3 +707,38 @@ def test_split_bf16_conv_transpose():
     finally:
         ops.set_option("split_bf16", 0)
     assert_close(y, torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2), 2e-6)
+
+
+@pytest.mark.parametrize("cfg", [(1, 70, 7, 63, 200), (1, 256, 8, 64, 256), (2, 20, 12, 37, 320)])
+def test_split_bf16_3x3_is_fp32_accurate(cfg):
+    """The nine-tap split-bf16 kernel (option value 2): zero padding through the buffer range check, the load-side
+    prologue applied by the split pass, specialised and generic epilogues."""
+    from cwfa_amd import ops
+    B, Cin, H, W, Cout = cfg
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    alpha = torch.tensor([0.2])
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
+    lin_pro = F.conv2d(xin, w.double(), b.double(), padding=1)
+    ops.set_option("split_bf16", 2)
+    try:
+        pc = ops.pack_conv_weight(w.cuda())
+        assert pc.split
+        got = {"plain": ops.conv2d(x.cuda(), pc, bias=b.cuda()),
+               "prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda()),
+               "generic": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="gelu", residual=res.cuda(), act2="relu"),
+               "pro_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
+                                       in_shift=sh.cuda(), in_add=add.cuda())}
+    finally:
+        ops.set_option("split_bf16", 0)
+    want = {"plain": ref, "prelu": F.prelu(ref, alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
+            "pro_prelu": F.prelu(lin_pro, alpha.double())}
+    for k in want:
+        assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")

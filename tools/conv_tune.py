@@ -12,8 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
-    "novload": ("conv_wino2d.hip", ["-DCWFA_EXP_NOVLOAD"]),
-    "novload_noxform": ("conv_wino2d.hip", ["-DCWFA_EXP_NOVLOAD", "-DCWFA_EXP_NOXFORM"]),
+    "base": ("conv2d.hip", []),
+    "nodma": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NODMA"]),
+    "nobar": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NOBAR"]),
+    "nodma_nobar": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NODMA", "-DCWFA_EXP_SPLIT_NOBAR"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
     (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
@@ -42,6 +44,7 @@ def run_one(name):
     _lib.LIB_PATH = os.path.join(VDIR, f"lib_{name}.so")
     from cwfa_amd import ops
     ops.set_option("winograd_2d", int(os.environ.get("CWFA_TUNE_2D", "1")))
+    ops.set_option("split_bf16", int(os.environ.get("CWFA_TUNE_SPLIT", "0")))
     res = {}
     for (cin, cout, H, W, ks) in SHAPES:
         x = torch.randn(1, cin, H, W, device="cuda")

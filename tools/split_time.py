@@ -30,3 +30,20 @@ for (cin, co, H, tr) in [(1024, 512, 128, True), (512, 256, 256, True), (256, 25
     ops.set_option("split_bf16", 0)
     d = float((res[1][1] - res[0][1]).abs().max() / res[0][1].abs().max())
     print(f"{'convT' if tr else '1x1'} {cin}->{cout} @{H}: fp32 {res[0][0]:.3f} ms ({fl/res[0][0]/1e9:.0f} TF)  split {res[1][0]:.3f} ms ({fl/res[1][0]/1e9:.0f} TF)  |split-fp32|/max {d:.1e}", flush=True)
+
+alpha = torch.tensor([0.25], device="cuda")
+for (cin, cout, H) in [(256, 256, 512), (512, 512, 256), (1024, 1024, 128)]:
+    x = torch.randn(1, cin, H, H, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+    sc, sh = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda")
+    fl = 2.0 * cin * cout * 9 * H * H
+    res = {}
+    for split in (0, 2):
+        ops.set_option("split_bf16", split)
+        pc = ops.pack_conv_weight(w)
+        f = lambda: ops.conv2d(x, pc, act="prelu", prelu_alpha=alpha, in_scale=sc, in_shift=sh)
+        y = f()
+        res[split] = (t(f), y)
+    ops.set_option("split_bf16", 0)
+    d = float((res[2][1] - res[0][1]).abs().max() / res[0][1].abs().max())
+    print(f"3x3 {cin}->{cout} @{H} (BN-on-load, PReLU): fp32 Winograd {res[0][0]:.3f} ms ({fl/res[0][0]/1e9:.0f} TF)  split {res[2][0]:.3f} ms ({fl/res[2][0]/1e9:.0f} TF)  |diff|/max {d:.1e}", flush=True)
