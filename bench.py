@@ -35,6 +35,8 @@ def family(key):
     ks, cin, cout, H, W, B, tag = key[:7]
     if ks == "L":
         return "wino_layer_kernel"
+    if tag.endswith("+split"):
+        return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout >= 33:
         return "conv3x3_wino_kernel<%s>[%s]" % ("W64" if cout <= 64 else "W128", tag)
     return "conv2d_mfma_kernel<k%d,%s>[%s]" % (ks, "co<=32" if cout <= 32 else "co<=64" if cout <= 64 else "co>64", tag)
@@ -194,8 +196,9 @@ def main():
             # to compare with the rocprofv3 kernel-stats average for the same kernel (profiles/).
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": dom + " (v_mfma_f32_32x32x2_f32" + (", Winograd F(2,3): 1.5x fewer MFMAs than the "
-                                   "algorithmic count" if "wino" in dom else "") + ")",
+                         "kernel": dom + (" (v_mfma_f32_32x32x16_bf16, six split products per algorithmic FMA)" if "split" in dom else
+                                          " (v_mfma_f32_32x32x2_f32" + (", Winograd F(2,3): 1.5x fewer MFMAs than the "
+                                          "algorithmic count" if "wino" in dom else "") + ")"),
                          "mfma_issued_frac": tf / (1.5 if "wino" in dom else 1.0) / PEAK_FP32_MFMA_TFLOPS,
                          "shapes": [dict(zip(("ks", "cin", "cout", "H", "W", "B", "launches"), (*k[:6], n)))
                                     for k, n in sorted(shapes.items(), key=lambda kv: -kv[1])],

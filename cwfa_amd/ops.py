@@ -304,7 +304,8 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         # the last field names the kernel instantiation the C side dispatches to (prologue / epilogue variant)
         key = (pc.ks, Cin, pc.cout, H, W, B, "%s|%s|%s|%s|%s" % ("pro" if (in_scale is not None or in_add is not None) else "",
                                                                  act or "", "res" if residual is not None else "", act2 or "",
-                                                                 "up" if up else ""), in_add is not None)
+                                                                 ("up" if up else "") + ("+split" if pc.split else "")),
+               in_add is not None)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
