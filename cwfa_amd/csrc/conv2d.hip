@@ -344,7 +344,6 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const Tile& t, f32
     if constexpr (EPI == EPI_GENERIC) {
         // runtime-switched path: the accumulators go through LDS so that ONE copy of the code serves all 64 of them
         const float alpha = (p.o.prelu_alpha && (p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU)) ? *p.o.prelu_alpha : 0.f;
-        const int Co = p.o.upshuffle2 ? p.Cout / 4 : p.Cout;
         const float* rb = p.o.residual ? p.o.residual + (int64_t)t.b * p.o.res_bs : nullptr;
         extern __shared__ __attribute__((aligned(16))) float smem[];
         __syncthreads();                                   // main loop done with the LDS tiles
@@ -1038,7 +1037,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
 
 template <int EPI, int KS>
 int launch_split(SplitParams sp, hipStream_t stream) {
-    dim3 grid;
     ConvParams& p = sp.c;
     p.tiles_x = (p.W + CS::TC - 1) / CS::TC;
     p.tiles_y = (p.H + CS::TR - 1) / CS::TR;

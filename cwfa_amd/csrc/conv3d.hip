@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void conv3d_1k1_kernel(const float* __restrict
 struct C3M {
     static constexpr int DT = 6, HT = 8, WT = 30, NTHREADS = 256, NWAVES = 4;
     static constexpr int XD = DT + 4, XH = HT + 4, XW = 36;     // staged input (origin -2), 34 used columns
-    static constexpr int HD = DT + 2, HH = HT + 2;               // hidden rows (origin -1), 32 columns
+    static constexpr int HD = DT + 2, HH = HT + 2;               // hidden slabs x rows (origin -1), 32 columns
+    static_assert(HD == 2 * NWAVES, "every wave owns two hidden slabs");
     static constexpr int XS = XD * XH * XW;
     // per-wave private output copy, padded so that NO scatter target needs a validity test: 4 depth slabs (a wave owns two
     // hidden slabs), HT + 4 rows, 32 + 2 (+2 pad) columns; contributions that fall outside the tile land in the padding
