@@ -68,6 +68,7 @@ SIGNATURES = {
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),
     "cwfa_conv_split_pack_f32": (i, [p, p, i, i, i, i, p]),
     "cwfa_conv_split_f32": (i, [p, p, p, i, i, i, i, i, i, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_conv3x3_split_fused_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

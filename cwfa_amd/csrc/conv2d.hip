@@ -899,12 +899,19 @@ __global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
 // weights arrive one 24.6 KB slice per tap-step through a three-buffer ring, two steps ahead.
 constexpr int CS3_XE = 3 * 2 * 10 * 34, CS3_XB = 2048 * 16;      // entries used / bytes reserved per input buffer (4 DMA items per thread)
 
-template <int EPI>
+// MODE 0: the input comes pre-split from cwfa_split_input_f32 (LDS-DMA).  MODE 1 / 2: the kernel reads the fp32 tensor
+// itself and splits on the way into LDS -- a thread owns one or two (k half, row, column) entries of the tile, loads
+// their 8 channels early in a chunk, and late in the chunk applies the load-side affine (scale / shift tables held in
+// LDS), adds the skip tensor (MODE 2), splits and writes three 16-byte entries: no workspace, no extra HBM pass.
+enum { SPLIT_PRE = 0, SPLIT_FUSED = 1, SPLIT_FUSED_ADD = 2 };
+constexpr int CS3_AFF = 2 * 2048 * 4;                            // bytes: scale / shift tables for up to 2048 input channels
+
+template <int EPI, int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
     typedef CS C;
     const ConvParams& p = sp.c;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);                   // [2 x CS3_XB input][3 x CS_WB weights]
+    char* lds = reinterpret_cast<char*>(smem);                   // [2 x CS3_XB input][3 x CS_WB weights][affine tables]
     const Tile t = make_tile<C>(p);
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t HW = (int64_t)p.H * p.W;
@@ -937,6 +944,75 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
                                                  chunk * xchunk, 0, 0);
     };
 
+    // ---- fused mode: entries e = tid and tid + 512 (< 680) of the [k half][10 rows][34 px] tile
+    constexpr bool FUSED = MODE != SPLIT_PRE, ADD = MODE == SPLIT_FUSED_ADD;
+    constexpr int NE = FUSED ? 2 : 1, NA = ADD ? 2 : 1;
+    unsigned fo[NE];
+    bool fok[NE], fin[NE];
+    float xv[NE][8], av[NA][8];
+    float* aff = reinterpret_cast<float*>(lds + 2 * CS3_XB + 3 * CS_WB);     // [scale 2048][shift 2048]
+    const bool has_aff = FUSED && p.o.in_scale != nullptr;
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + k * 512;
+            const int c = e % 34, r = (e / 34) % 10, h = (e / 340) & 1;
+            const int gr = t.row0 + r - 1, gc = t.col0 + c - 1;
+            fin[k] = e < 680;
+            fok[k] = fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
+            fo[k] = fok[k] ? (unsigned)(((int64_t)h * 8 * HW + (int64_t)gr * p.W + gc) * 4) : OOB;
+        }
+        if (has_aff) {
+            const float* sc = p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs;
+            const float* sh = p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs;
+            for (int c = tid; c < 2048; c += 512) {
+                aff[c] = c < p.Cin ? sc[c] : 0.f;
+                aff[2048 + c] = c < p.Cin ? sh[c] : 0.f;
+            }
+        }
+    }
+    const int fbytes = (int)((int64_t)p.Cin * HW * 4);
+    const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, FUSED ? fbytes : 0, 0x00020000);
+    const auto rfa = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ADD ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : p.x), 0, ADD ? fbytes : 0, 0x00020000);
+    const int plane = (int)(HW * 4);
+    auto ldf = [](decltype(rf) r, unsigned vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
+    auto load_entry = [&](auto kc, int chunk) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[k][j] = ldf(rf, fo[k], (chunk * 16 + j) * plane);
+        if constexpr (ADD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[k][j] = ldf(rfa, fo[k], (chunk * 16 + j) * plane);
+        }
+    };
+    auto store_entry = [&](auto kc, int chunk, int xbuf) {
+        constexpr int k = decltype(kc)::value;
+        const int e = tid + k * 512;
+        const int ch0 = chunk * 16 + ((e / 340) & 1) * 8;
+        unsigned short pc[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = xv[k][j];
+            if (has_aff) v = fok[k] ? v * aff[(ch0 + j) & 2047] + aff[2048 + ((ch0 + j) & 2047)] : 0.f;     // padding stays zero
+            if constexpr (ADD) v += av[k][j];
+            unsigned short o[3];
+            split3(v, o);
+            pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
+        }
+        if (fin[k]) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                uint4 u;
+                u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
+                u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
+                u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
+                u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
+                *reinterpret_cast<uint4*>(lds + xbuf * CS3_XB + (q * 680 + e) * 16) = u;
+            }
+        }
+    };
+
     f32x16 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -948,11 +1024,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
     const char* alane = lds + 2 * CS3_XB + ((t.kh * 256) + t.wm * 64 + t.l31) * 16;          // + wbuf*CS_WB + (piece*512 + m*32)*16
     const char* blane = lds + ((t.kh * 10 + t.wn * 4) * 34 + t.l31) * 16;                     // + xbuf*CS3_XB + (piece*680 + (n+dy)*34 + dx)*16
 
+    if constexpr (FUSED) {
+        __syncthreads();                                  // affine tables
+        load_entry(sc_int<0>{}, 0);
+        load_entry(sc_int<1>{}, 0);
+        store_entry(sc_int<0>{}, 0, 0);
+        store_entry(sc_int<1>{}, 0, 0);
+        dma_w(0, 0);
+        dma_w(1, 1);
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_x(i, 0, 0);
-    dma_w(0, 0);
-    dma_w(1, 1);
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        for (int i = 0; i < 4; ++i) dma_x(i, 0, 0);
+        dma_w(0, 0);
+        dma_w(1, 1);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     // Operand registers: two A sets (the set of step t+1 is read in the second half of step t, AFTER the mid-step barrier
     // that makes weight slice t+1 visible), B ring of two (the first B fragment of step t+1 is read during the last
@@ -982,7 +1069,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
             nb = nb >= 3 ? nb - 3 : nb;
 #ifndef CWFA_EXP_SPLIT_NODMA
             dma_w(step + 2, nb);
-            if constexpr (tap < 4) dma_x(tap, chunk + 1, (chunk + 1) & 1);      // next chunk's input tile, one item per step
+            if constexpr (!FUSED) {
+                if constexpr (tap < 4) dma_x(tap, chunk + 1, (chunk + 1) & 1);  // next chunk's input tile, one item per step
+            } else {
+                // next chunk's entries: loads in the first two steps (past the last chunk: out of range, zeros), split and
+                // LDS stores in steps 6 and 7 -- before the barrier of step 8 that precedes the first read of that buffer
+                if constexpr (tap == 0) load_entry(sc_int<0>{}, chunk + 1);
+                if constexpr (tap == 1) load_entry(sc_int<1>{}, chunk + 1);
+                if constexpr (tap == 6) store_entry(sc_int<0>{}, chunk + 1, (chunk + 1) & 1);
+                if constexpr (tap == 7) store_entry(sc_int<1>{}, chunk + 1, (chunk + 1) & 1);
+            }
 #endif
             int w1 = wbuf + 1;
             w1 = w1 == 3 ? 0 : w1;
@@ -1000,8 +1096,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
                 if (n == 2) {
                     // weight slice step+1 (issued one step ago) has landed everywhere; this step's own DMAs may stay in flight
 #ifndef CWFA_EXP_SPLIT_NODMA
-                    if constexpr (tap < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    // allowed in flight: this step's own loads (3 weight DMAs + its input items)
+                    if constexpr (!FUSED) {
+                        if constexpr (tap < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else if constexpr (tap < 2 && ADD) {
+                        asm volatile("s_waitcnt vmcnt(19)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else if constexpr (tap < 2) {
+                        asm volatile("s_waitcnt vmcnt(11)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
 #endif
 #ifndef CWFA_EXP_SPLIT_NOBAR
                     __builtin_amdgcn_s_barrier();
@@ -1035,7 +1140,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
     epilogue<C, EPI>(p, t, acc);
 }
 
-template <int EPI, int KS>
+template <int EPI, int KS, int MODE = SPLIT_PRE>
 int launch_split(SplitParams sp, hipStream_t stream) {
     ConvParams& p = sp.c;
     p.tiles_x = (p.W + CS::TC - 1) / CS::TC;
@@ -1043,8 +1148,8 @@ int launch_split(SplitParams sp, hipStream_t stream) {
     const int ctiles = (p.Cout + CS::CT - 1) / CS::CT;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
                  "cwfa_conv1x1_split_f32: grid too large");
-    constexpr int LDS = KS == 1 ? 3 * CS_BUFB : 2 * CS3_XB + 3 * CS_WB;
-    auto kern = KS == 1 ? &conv1x1_split_kernel<EPI> : &conv3x3_split_kernel<EPI>;
+    constexpr int LDS = KS == 1 ? 3 * CS_BUFB : 2 * CS3_XB + 3 * CS_WB + (MODE != SPLIT_PRE ? CS3_AFF : 0);
+    auto kern = KS == 1 ? &conv1x1_split_kernel<EPI> : &conv3x3_split_kernel<EPI, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1131,6 +1236,35 @@ extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* 
         case EPI_NONE: return launch_split<EPI_NONE, 3>(sp, st);
         case EPI_PRELU: return launch_split<EPI_PRELU, 3>(sp, st);
         default: return launch_split<EPI_GENERIC, 3>(sp, st);
+    }
+}
+
+extern "C" int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                                            int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "cwfa_conv3x3_split_fused_f32: null pointer");
+    SplitParams sp{};
+    int rc = fill_params(sp.c, "cwfa_conv3x3_split_fused_f32", x, reinterpret_cast<const float*>(w_packed), y, B, Cin, H, W, Cout, x_bs,
+                         y_bs, opts);
+    if (rc) return rc < 0 ? rc : CWFA_OK;
+    ConvParams& p = sp.c;
+    CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_fused_f32: upshuffle2 is a 1x1 feature");
+    CWFA_REQUIRE(Cin <= 2032, CWFA_E_SHAPE, "cwfa_conv3x3_split_fused_f32: at most 2032 input channels (affine tables in LDS)");
+    p.nchunks = (Cin + 15) / 16;
+    CWFA_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(p.nchunks * 9 + 2) * CS_WB < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv3x3_split_fused_f32: one sample's input / one cout tile's weights must stay below 2 GiB");
+    const int epi = classify_epilogue(p.o);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.o.in_add) {
+        switch (epi) {
+            case EPI_NONE: return launch_split<EPI_NONE, 3, SPLIT_FUSED_ADD>(sp, st);
+            case EPI_PRELU: return launch_split<EPI_PRELU, 3, SPLIT_FUSED_ADD>(sp, st);
+            default: return launch_split<EPI_GENERIC, 3, SPLIT_FUSED_ADD>(sp, st);
+        }
+    }
+    switch (epi) {
+        case EPI_NONE: return launch_split<EPI_NONE, 3, SPLIT_FUSED>(sp, st);
+        case EPI_PRELU: return launch_split<EPI_PRELU, 3, SPLIT_FUSED>(sp, st);
+        default: return launch_split<EPI_GENERIC, 3, SPLIT_FUSED>(sp, st);
     }
 }
 

@@ -309,7 +309,11 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-    if pc.split:
+    if pc.split and pc.ks == 3 and _split_bf16 != 3:
+        # fp32-accurate conv on the bf16 pipe, the kernel splits x on the way into LDS (prologue included)
+        check(L.cwfa_conv3x3_split_fused_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o),
+                                             _stream()), "conv3x3_split_fused")
+    elif pc.split:
         # fp32-accurate GEMM on the bf16 pipe: one pass splits x (with the load-side prologue) into three bf16 planes
         ws = torch.empty(L.cwfa_split_workspace_bytes(B, Cin, H * W), dtype=torch.uint8, device=x.device)
         per_sample = in_scale is not None and in_scale.numel() == B * Cin and B > 1
@@ -511,6 +515,7 @@ def set_option(name, value):
     global _split_bf16, _pack_epoch
     _pack_epoch += 1
     if name == "split_bf16":          # 0 off, 1: 1x1 / transposed convs, 2: also 3x3 convs with >= 192 output channels
+        #                                 (3: as 2 but the 3x3 kernel reads pre-split planes: the A/B reference for 2)
         _split_bf16 = int(value)
         return
     check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")

@@ -251,6 +251,10 @@ int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, int64_t HW, i
                          const float* in_shift, int64_t in_affine_bs, const float* in_add, int64_t in_add_bs, void* stream);
 int64_t cwfa_conv_split_packed_bytes(int Cout, int Cin, int ks);
 int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int ks, int transposed, void* stream);
+/* 3x3 only: the same computation straight from the fp32 tensor (the kernel splits on the way into LDS and applies the
+ * load-side affine / added tensor of `opts` itself): no workspace, no extra pass. */
+int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                                 int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 

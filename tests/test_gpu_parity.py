@@ -709,8 +709,9 @@ def test_split_bf16_conv_transpose():
     assert_close(y, torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2), 2e-6)
 
 
+@pytest.mark.parametrize("level", [2, 3])
 @pytest.mark.parametrize("cfg", [(1, 70, 7, 63, 200), (1, 256, 8, 64, 256), (2, 20, 12, 37, 320)])
-def test_split_bf16_3x3_is_fp32_accurate(cfg):
+def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
     """The nine-tap split-bf16 kernel (option value 2): zero padding through the buffer range check, the load-side
     prologue applied by the split pass, specialised and generic epilogues."""
     from cwfa_amd import ops
@@ -727,7 +728,7 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
     lin_pro = F.conv2d(xin, w.double(), b.double(), padding=1)
-    ops.set_option("split_bf16", 2)
+    ops.set_option("split_bf16", level)       # 2: the kernel splits on the fly, 3: pre-split planes
     try:
         pc = ops.pack_conv_weight(w.cuda())
         assert pc.split
@@ -735,10 +736,13 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
                "prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda()),
                "generic": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="gelu", residual=res.cuda(), act2="relu"),
                "pro_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
-                                       in_shift=sh.cuda(), in_add=add.cuda())}
+                                       in_shift=sh.cuda(), in_add=add.cuda()),
+               "aff_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
+                                       in_shift=sh.cuda())}
     finally:
         ops.set_option("split_bf16", 0)
+    lin_aff = F.conv2d(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), w.double(), b.double(), padding=1)
     want = {"plain": ref, "prelu": F.prelu(ref, alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
-            "pro_prelu": F.prelu(lin_pro, alpha.double())}
+            "pro_prelu": F.prelu(lin_pro, alpha.double()), "aff_prelu": F.prelu(lin_aff, alpha.double())}
     for k in want:
         assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")

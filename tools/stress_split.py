@@ -10,7 +10,7 @@ for it in range(30):
     H = random.randint(1, 40); W = random.randint(1, 90)
     x = torch.randn(B, Cin, H, W); w = torch.randn(Cout, Cin, ks, ks) / (Cin * ks * ks) ** 0.5; b = torch.randn(Cout)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
-    ops.set_option("split_bf16", 2)
+    ops.set_option("split_bf16", random.choice([2, 3]))
     pc = ops.pack_conv_weight(w.cuda()); assert pc.split
     y = ops.conv2d(x.cuda(), pc, bias=b.cuda())
     ops.set_option("split_bf16", 0)
