@@ -224,7 +224,10 @@ def main():
                                       "share_of_conv_time": tot[ranked[1]][0] / all_conv_ms}
         res["roofline_dwt"] = dwt_roofline(ops, a, dev)
         if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
-            res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3))
+            try:                                              # never let the side experiment cost the headline line
+                res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3))
+            except Exception as exc:                          # noqa: BLE001
+                res["experiment_split_bf16"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
             res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
         print(json.dumps(res), flush=True)
