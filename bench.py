@@ -229,7 +229,10 @@ def main():
             except Exception as exc:                          # noqa: BLE001
                 res["experiment_split_bf16"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
-            res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
+            try:
+                res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
+            except Exception as exc:                          # noqa: BLE001  (host trouble must not lose the GPU measurement)
+                res["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(exc)[:200]}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
