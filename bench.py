@@ -163,7 +163,7 @@ def main():
         step()
 
     ranked = sorted(tot, key=lambda k: -tot[k][0])
-    sink = ops.conv_event_sink = ConvEvents(only=set(ranked[:2]))    # the dominant kernel and the runner-up
+    sink = ops.conv_event_sink = ConvEvents(only={dom})       # only the dominant kernel carries events in the timed region
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -210,8 +210,13 @@ def main():
                                  "this fp32 metric, hence vs_baseline is null"},
         }
         res["roofline"]["traffic"], res["roofline"]["traffic_detail"] = pmc_traffic(dom, a)
-        if len(ranked) > 1 and ranked[1] in sink.totals():          # the runner-up kernel, same definitions
-            t2, n2, f2, sh2 = sink.totals()[ranked[1]]
+        if len(ranked) > 1:                                        # the runner-up kernel, same definitions, timed in three
+            sink2 = ops.conv_event_sink = ConvEvents(only={ranked[1]})   # extra steps AFTER the timed region (its many small
+            for _ in range(3):                                     # launches would otherwise put ~1 % of event gaps into `value`)
+                step()
+            torch.cuda.synchronize()
+            ops.conv_event_sink = None
+            t2, n2, f2, sh2 = sink2.totals()[ranked[1]]
             tf2 = f2 / (t2 * 1e-3) / 1e12
             tr2, td2 = pmc_traffic(ranked[1], a)
             res["roofline_second"] = {"bound": "mfma", "achieved": tf2, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
