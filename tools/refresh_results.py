@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(ROOT, "profiles/r01_v3_bench.json")))
 r = d["roofline"]
 rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles/r01_v3_bench_kernel_stats.csv"))))
-steps = 13                                             # prof_bench.sh: 10 timed + 3 warm-up/selection passes
+steps = 16                                             # prof_bench.sh: 10 timed + 3 warm-up/selection + 3 runner-up passes
 tot = sum(float(x["TotalDurationNs"]) for x in rows) / steps / 1e6
 lines = ["| `%s` | %d | %.2f | %.1f |" % (x["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70],
                                           int(x["Calls"]) // steps, float(x["TotalDurationNs"]) / steps / 1e6, float(x["Percentage"]))
