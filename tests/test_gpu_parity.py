@@ -746,3 +746,55 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
             "pro_prelu": F.prelu(lin_pro, alpha.double()), "aff_prelu": F.prelu(lin_aff, alpha.double())}
     for k in want:
         assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")
+
+
+# ------------------------------------------------------------------------------------------------ sharded NLL on the GPU path
+def _nll_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # one card here: gloo (RCCL needs one GPU per rank)
+    try:
+        fx = load_golden("g10_pipeline")
+        CWFA, conv_inn, cond_nets, S = _pipeline(fx)
+        x = torch.from_numpy(fx["gt"]).cuda()
+        g0 = torch.Generator().manual_seed(5)
+        c = [torch.randn(x.shape[0], 8, *x.shape[2:], generator=g0).cuda(), 0.1 * torch.randn(x.shape[0], 8, *x.shape[2:], generator=g0).cuda()]
+        B = x.shape[0]
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        with torch.no_grad():
+            nll, _, _ = CWFA.nll_step(conv_inn[0], x[lo:hi].contiguous(), [t[lo:hi].contiguous() for t in c])
+            dist.barrier()
+        q.put((rank, float(nll)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_nll_two_ranks_on_the_gpu_path():
+    """SURVEY.md 8(e) through the product: two processes share this card, each runs the fused forward chain on its half
+    of the batch, one all-reduce of the float64[3] shard sums, both obtain the single-process NLL."""
+    import socket
+    import torch.multiprocessing as mp
+    fx = load_golden("g10_pipeline")
+    if fx["gt"].shape[0] < 2:
+        pytest.skip("fixture batch too small to shard")
+    CWFA, conv_inn, cond_nets, S = _pipeline(fx)
+    x = torch.from_numpy(fx["gt"]).cuda()
+    g0 = torch.Generator().manual_seed(5)
+    c = [torch.randn(x.shape[0], 8, *x.shape[2:], generator=g0).cuda(), 0.1 * torch.randn(x.shape[0], 8, *x.shape[2:], generator=g0).cuda()]
+    with torch.no_grad():
+        ref, _, _ = CWFA.nll_step(conv_inn[0], x, c)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nll_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    for _, nll in res:
+        assert abs(nll - float(ref)) <= 1e-6 * abs(float(ref)), (nll, float(ref))
