@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "pack_1x1_panel", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -345,6 +345,17 @@ def pack_1x1_panel(w):
     return PackedConv(panel, 64, 64, 1, False, w._version, w.data_ptr())
 
 
+def pack_split_layer_weight(w):
+    """[64,64,3,3] filter -> the split-bf16 image of the experimental fused layer (set_option("split_bf16", 2))."""
+    L = _lib.lib()
+    w = _dev(w, "weight").detach().contiguous()
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise ValueError("pack_split_layer_weight: 64x64x3x3 only")
+    packed = torch.empty(4 * 9 * 6144, dtype=torch.uint8, device=w.device)
+    check(L.cwfa_subnet_split_pack3x3_f32(_p(w), _p(packed), _stream()), "subnet_split_pack3x3")
+    return PackedConv(packed, 64, 64, 3, False, w._version, w.data_ptr(), split=True)
+
+
 def subnet_layer(x, pc3, b3, panel1, b1):
     """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch."""
     L = _lib.lib()
@@ -353,6 +364,10 @@ def subnet_layer(x, pc3, b3, panel1, b1):
     if Cc != 64 or pc3.cin != 64 or pc3.cout != 64 or pc3.ks != 3:
         raise ValueError("subnet_layer: 64-channel 3x3 layers only")
     out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+    if pc3.split:
+        check(L.cwfa_subnet_layer_split_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
+                                            xbs, 64 * H * W, _stream()), "subnet_layer_split")
+        return out
     rec = conv_event_sink
     if rec is not None:
         key = ("L", 64, 64, H, W, B, "layer", False)

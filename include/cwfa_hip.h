@@ -258,6 +258,13 @@ int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y,
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 
+/* EXPERIMENTAL: the fused sub-network layer (cwfa_subnet_layer_f32) with its 3x3 convolution on the split-bf16 core:
+ * w3_split = cwfa_subnet_split_pack3x3_f32(torch weight [64,64,3,3]) (221184 bytes, 16-byte aligned); the 1x1 panel as for
+ * cwfa_subnet_layer_f32. */
+int cwfa_subnet_split_pack3x3_f32(const float* w, void* packed, void* stream);
+int cwfa_subnet_layer_split_f32(const float* x, const void* w3_split, const float* b3, const float* w1_panel, const float* b1,
+                                float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Lenslet views (the step before the path): XLFMDatasetFull.extract_views XLFMDataset.py:212-242 followed by the
  * normalisation of CWFA.py:796-797.  image [B,1,Hs,Ws] (batch stride image_bs), coords_yx int32 [nviews][2] (device),

@@ -798,3 +798,19 @@ def test_sharded_nll_two_ranks_on_the_gpu_path():
         assert p_.exitcode == 0
     for _, nll in res:
         assert abs(nll - float(ref)) <= 1e-6 * abs(float(ref)), (nll, float(ref))
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96)])
+def test_split_fused_layer_is_fp32_accurate(shape):
+    """The fused sub-network layer with its 3x3 on the split-bf16 core (experimental): same reference, same tolerance."""
+    from cwfa_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W + 1)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w3, b3 = torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g) * 0.1
+    w1, b1 = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1
+    F = torch.nn.functional
+    xd = x.double()
+    ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
+    y = ops.subnet_layer(x.cuda(), ops.pack_split_layer_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()), b1.cuda())
+    assert_close(y, ref, 3e-6, "split fused layer")

@@ -47,3 +47,13 @@ for (cin, cout, H) in [(256, 256, 512), (512, 512, 256), (1024, 1024, 128)]:
     ops.set_option("split_bf16", 0)
     d = float((res[2][1] - res[0][1]).abs().max() / res[0][1].abs().max())
     print(f"3x3 {cin}->{cout} @{H} (BN-on-load, PReLU): fp32 Winograd {res[0][0]:.3f} ms ({fl/res[0][0]/1e9:.0f} TF)  split {res[2][0]:.3f} ms ({fl/res[2][0]/1e9:.0f} TF)  |diff|/max {d:.1e}", flush=True)
+
+x = torch.randn(1, 64, 512, 512, device="cuda")
+w3, b3 = torch.randn(64, 64, 3, 3, device="cuda") / 24, torch.randn(64, device="cuda") * 0.1
+w1, b1 = torch.randn(64, 64, 1, 1, device="cuda") / 8, torch.randn(64, device="cuda") * 0.1
+pn = ops.pack_1x1_panel(w1)
+pa, pb = ops.pack_conv_weight(w3), ops.pack_split_layer_weight(w3)
+ya, yb = ops.subnet_layer(x, pa, b3, pn, b1), ops.subnet_layer(x, pb, b3, pn, b1)
+ta, tb = t(lambda: ops.subnet_layer(x, pa, b3, pn, b1), 20), t(lambda: ops.subnet_layer(x, pb, b3, pn, b1), 20)
+fl = 2.0 * 64 * 64 * 10 * 512 * 512
+print(f"fused layer 64ch @512: fp32 Winograd {1e3*ta:.1f} us ({fl/ta/1e9:.0f} TF)  split {1e3*tb:.1f} us ({fl/tb/1e9:.0f} TF)  |diff|/max {float((ya-yb).abs().max()/ya.abs().max()):.1e}", flush=True)
