@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
 // accumulators are its B operand register by register, exactly as in subnet_layer_kernel above (eight passes of 32
 // chained MFMAs; bias, residual, ELU and the store of pass q-1 are slotted under the MFMAs of pass q).
 typedef Cfg<1, 16, 2, 4, 1, 8> CSL;
-constexpr int SL_XE = 2 * 34 * 34, SL_XPB = SL_XE * 16, SL_XB = 3 * SL_XPB, SL_WB = 3 * 2 * 64 * 16, SL_LDS = SL_XB + 3 * SL_WB;
+constexpr int SL_XE = 2 * 34 * 34, SL_XPB = SL_XE * 16, SL_XB = 3 * SL_XPB, SL_WB = 3 * 2 * 64 * 16, SL_LDS = SL_XB + 3 * SL_WB + 2048;
 
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
     typedef CSL C;
@@ -1205,10 +1205,13 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
         }
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto dma_w = [&](int step, int wbuf) {        // 384 entries of 16 B: waves 0..5 issue one item each; past the end: zeros
-        if (wave < 6)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + SL_XB + wbuf * SL_WB + wave * 1024), 16, (unsigned)tid * 16u,
-                                                     step * SL_WB, 0, 0);
+    // 384 entries of 16 B per slice: waves 0..5 carry it; waves 6, 7 issue the same instruction into a 2 KB dump area past the
+    // ring with an out-of-range offset (zeros), so that the step has no branch in it
+    const int dma_dst = wave < 6 ? wave * 1024 : 3 * SL_WB + (wave - 6) * 1024 - SL_WB * 0;
+    const unsigned dma_off = wave < 6 ? (unsigned)tid * 16u : OOB;
+    auto dma_w = [&](int step, int wbuf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + SL_XB + (wave < 6 ? wbuf * SL_WB : 0) + dma_dst), 16, dma_off,
+                                                 step * SL_WB, 0, 0);
     };
 
     f32x16 acc[2][4];
@@ -1232,37 +1235,40 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
     for (int chunk = 0; chunk < 4; ++chunk) {
         static_for<9>([&](auto tc) {
             constexpr int tap = decltype(tc)::value, dy = tap / 3, dx = tap % 3;
+            // All eight waves leave the barrier together and want 12 KB of operands each: issue the reads in the order the
+            // MFMAs consume them (the first needs two of the twelve), so the matrix pipe starts after 2 reads, not 12.
+            const char* ab = alane + wbuf * SL_WB;
+            bf16x8 A[2][3], Bq[2][3];
+            auto rdA = [&](int m, int q) { A[m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 128 + m * 32) * 16); };
+            auto rdB = [&](int n, int q) { Bq[n & 1][q] = *reinterpret_cast<const bf16x8*>(blane + q * SL_XPB + ((n + dy) * 34 + dx) * 16); };
+            rdA(0, 2); rdB(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(1, 2); rdA(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(1, 1); rdA(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(1, 0); rdB(0, 1); rdB(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
             int nb = wbuf + 2;
             nb = nb >= 3 ? nb - 3 : nb;
             dma_w(step + 2, nb);
             if constexpr (tap < 5) load_entry(sc_int<tap>{}, chunk + 1);        // past the last chunk: out of range, zeros, never stored
-            const char* ab = alane + wbuf * SL_WB;
-            bf16x8 A[2][3], Bq[2][3];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) A[m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 128 + m * 32) * 16);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) Bq[0][q] = *reinterpret_cast<const bf16x8*>(blane + q * SL_XPB + (dy * 34 + dx) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#define SL_MFMA(m, n, qa, qb)                                                                                             \
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][qa], Bq[(n) & 1][qb], acc[m][n], 0, 0, 0);                    \
+    __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                if (n < 3) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        Bq[(n + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(blane + q * SL_XPB + ((n + 1 + dy) * 34 + dx) * 16);
+                SL_MFMA(0, n, 2, 0); SL_MFMA(1, n, 2, 0); SL_MFMA(0, n, 1, 0); SL_MFMA(1, n, 1, 0);
+                SL_MFMA(0, n, 0, 0); SL_MFMA(1, n, 0, 0);
+                SL_MFMA(0, n, 1, 1); SL_MFMA(1, n, 1, 1); SL_MFMA(0, n, 0, 1); SL_MFMA(1, n, 0, 1);
+                if (n < 3) {                 // Bq[(n+1)&1] was last read by step-part n-1
+                    rdB(n + 1, 0); rdB(n + 1, 1); rdB(n + 1, 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    f32x16 c = acc[m][n];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][2], Bq[n & 1][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][0], c, 0, 0, 0);
-                    acc[m][n] = c;
-                }
+                SL_MFMA(0, n, 0, 2); SL_MFMA(1, n, 0, 2);
             }
+#undef SL_MFMA
             // weight slice step+1 (issued one step ago) has landed; this step's own loads (1 DMA, 8 input loads in the
             // first five taps) may stay in flight
             if constexpr (tap < 5) asm volatile("s_waitcnt vmcnt(9)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");

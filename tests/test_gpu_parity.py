@@ -748,6 +748,23 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
         assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")
 
 
+def test_split_bf16_subnetwork_matches_the_fp32_path():
+    """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
+    split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
+    from cwfa_amd import networks as N, ops
+    torch.manual_seed(4)
+    net = N.wavelet_flow_subnetwork2D(58, 24).cuda()
+    x = torch.randn(2, 58, 75, 41, device="cuda")
+    with torch.no_grad():
+        ref = net(x)
+        ops.set_option("split_bf16", 2)
+        try:
+            got = net(x)
+        finally:
+            ops.set_option("split_bf16", 0)
+    assert_close(got, ref, 5e-6, "sub-network, split level 2")
+
+
 # ------------------------------------------------------------------------------------------------ sharded NLL on the GPU path
 def _nll_rank(rank, world, port, q):
     import os
