@@ -13,7 +13,7 @@ import torch
 from . import ops
 
 __all__ = ["sample_z_truncated", "check_empty_depths", "evaluate_INN_forward", "inverse_pass", "nll_step",
-           "nll_terms", "allreduce_nll", "build_networks"]
+           "nll_terms", "allreduce_nll", "build_networks", "step_log_likelihoods", "allgather_scores", "detect_ood"]
 
 
 def _no_grad_trunc_normal_(tensor, mean=0., std=1., a=-1., b=1.):
@@ -100,6 +100,61 @@ def evaluate_INN_forward(conv_inn, cond_nets, args_general, args_nets, gt_volume
             gt_volume = Z[1]
             gt_cache[n_net + 1] = gt_volume
     return losses, gt_cache, prior_errors, log_jacobians
+
+
+def step_log_likelihoods(conv_inn, cond_nets, args_general, gt_volume, input_views, train_statistics, extra_cond_in=None,
+                         group=None):
+    """Per-sample, per-step log-likelihoods of a batch under the flows: LL[b, n] = -(0.5*||z_b||^2 - logdet_b) / numel_b
+    -- the per-volume form of ``evaluate_INN_forward``'s losses (CWFA.py:183-186; for a batch of one, LL[0, n] is
+    exactly -losses[n]).  This is the score the reference thresholds for out-of-distribution detection
+    (main.py:78-80: ``--step_LL_to_use``, ``--step_LL_ths_to_use``; its evaluator ``main_OOD`` is not part of the
+    released sources, main.py:16,401).  One fused forward chain per step; the per-sample sums of squares are one
+    extra read of Z0 (``sample_stats``).  With a process group every rank scores its shard and the [B_local, S] blocks
+    are all-gathered in rank order (RCCL on MI355X): every rank returns the scores of the global batch.
+    Returns a float64 tensor [B, len(conv_inn)]."""
+    device = gt_volume.device
+    gt_volume = check_empty_depths(gt_volume)
+    cond_input = (input_views - train_statistics[0]) / train_statistics[1]
+    B = gt_volume.shape[0]
+    cols = []
+    for n_net, g in enumerate(conv_inn):
+        is_last_step = n_net == args_general.INN_max_down_steps - 1
+        if is_last_step:
+            cond_in = [] if args_general.force_all_steps_NF else [cond_nets[n_net](cond_input)[-1]]
+        else:
+            cond_in = [torch.zeros((B,) + tuple(g.dims_c[0]), device=device)] if len(g.dims_c) > 0 else []
+        if len(g.dims_c) > 1:
+            cond_in.append(torch.zeros((B,) + tuple(g.dims_c[1]), device=device) if extra_cond_in is None
+                           else extra_cond_in[n_net].clone())
+        Z, logdet = g(gt_volume, c=cond_in)
+        sumsq = ops.sample_stats(Z[0]).view(B, 2)[:, 1]
+        cols.append(-(0.5 * sumsq - logdet.to(torch.float64)) / Z[-1][0].numel())
+        if not is_last_step:
+            gt_volume = Z[1]
+    return allgather_scores(torch.stack(cols, 1), group)
+
+
+def allgather_scores(scores, group=None):
+    """Concatenate the ranks' [B_local, S] score blocks in rank order (shards may differ in size); no-op without
+    torch.distributed.  Two small all-gathers: the shard sizes, then the blocks padded to the largest shard."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return scores
+    device, B = scores.device, scores.shape[0]
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(counts, torch.tensor([B], dtype=torch.int64, device=device), group=group)
+    counts = [int(c_) for c_ in counts]
+    padded = torch.zeros(max(counts), scores.shape[1], dtype=scores.dtype, device=device)
+    padded[:B] = scores
+    blocks = [torch.empty_like(padded) for _ in counts]
+    dist.all_gather(blocks, padded, group=group)
+    return torch.cat([blk[:c_] for blk, c_ in zip(blocks, counts)], 0)
+
+
+def detect_ood(scores, step_LL_to_use=0, step_LL_ths_to_use=-1.33):
+    """Out-of-distribution flags from ``step_log_likelihoods``: a sample is flagged when the log-likelihood of step
+    ``step_LL_to_use`` falls below the threshold (defaults of main.py:79-80)."""
+    return scores[:, step_LL_to_use] < step_LL_ths_to_use
 
 
 def inverse_pass(conv_inn, cond_nets, cond_input, mean_vols_cache, low=None, temperature=0.0, n_samples=1,

@@ -433,6 +433,12 @@ def nll_from_terms(sumsq: float, sumlogdet: float, B: int, numel_total: int) -> 
     return (0.5 * sumsq - sumlogdet / B) / numel_total
 
 
+def step_log_likelihood(z: Tensor, logdet: Tensor, numel_per_sample: int) -> Tensor:
+    """Per-sample log-likelihood of one step, float64[B]: -(0.5*||z_b||^2 - logdet_b) / numel_b -- CWFA.py:183-186 with
+    the norm taken per volume (for B = 1 it is -curr_LL_loss); the score main.py:78-80 thresholds."""
+    return -(0.5 * z.double().flatten(1).pow(2).sum(1) - logdet.double()) / numel_per_sample
+
+
 def inverse_pass(steps: Sequence[dict], low: Tensor, cond_input: Tensor, mean_cache: Sequence[Tensor],
                  lrnn_sd: Optional[SD] = None, lrnn_train: bool = False) -> List[Tensor]:
     """The reconstruction loop, T=0 (z = 0), n_samples=1.  CWFA.py:865-924.

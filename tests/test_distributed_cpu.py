@@ -59,3 +59,48 @@ def test_sharded_nll_two_ranks_gloo():
         assert n == 2
         assert abs(nll - ref) <= 1e-5 * abs(ref), (nll, ref)
     assert res[0][1] == res[1][1], "every rank must hold the identical global NLL"
+
+
+def _score_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cwfa_amd.CWFA import allgather_scores, detect_ood
+        from oracle import cwfa_oracle as O
+        fx = load_golden("g09_step_CAT_k0")
+        sd = sd_of(fx)
+        axes = {i: 1 for i in range(3, 12, 2)}
+        axes.update({int(k.split("_")[-1]): int(v) for k, v in fx.items() if k.startswith("meta/axis_")})
+        x, c = torch.from_numpy(fx["x"]), [torch.from_numpy(fx["c0"]), torch.from_numpy(fx["c1"])]
+        x, c = torch.cat([x, 0.5 * x, -x], 0), [torch.cat([t, t, t], 0) for t in c]      # 3B samples, uneven shards
+        B = x.shape[0]
+        lo, hi = (0, B // 3) if rank == 0 else (B // 3, B)
+        (z, low), jac = O.flow_step(sd, x[lo:hi], [t[lo:hi] for t in c], False, axes)
+        local = O.step_log_likelihood(z, jac, low[0].numel()).view(-1, 1)
+        scores = allgather_scores(local)
+        (zf, lowf), jf = O.flow_step(sd, x, c, False, axes)
+        ref = O.step_log_likelihood(zf, jf, lowf[0].numel()).view(-1, 1)
+        flags = detect_ood(scores, 0, float(ref.median()))
+        q.put((rank, scores.tolist(), ref.tolist(), flags.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ood_scores_two_ranks_gloo():
+    """SURVEY.md 8(f)4 over 8(e)'s sharding: uneven batch shards, per-sample step log-likelihoods all-gathered in rank
+    order; every rank holds the single-process scores of the whole batch."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_score_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, scores, ref, flags in res:
+        assert len(scores) == len(ref)
+        assert torch.allclose(torch.tensor(scores), torch.tensor(ref), rtol=1e-9, atol=0)
+        assert 0 < sum(flags) < len(flags)
+    assert res[0][1] == res[1][1]

@@ -431,6 +431,25 @@ def test_pipeline_golden():
         assert abs(float(losses[n]) - fx["losses"][n]) <= TOL * abs(fx["losses"][n])
         assert abs(float(prior[n]) - fx["prior"][n]) <= TOL * abs(fx["prior"][n])
         assert abs(float(logj[n]) - fx["logjac"][n]) <= TOL * abs(fx["logjac"][n]) + 1e-9
+    # per-sample, per-step log-likelihoods (OOD score): against the oracle, and for a batch of one against -losses
+    from oracle import cwfa_oracle as O
+    ll = CWFA.step_log_likelihoods(conv_inn, cond_nets, args, cu(fx["gt"]).clone(), cu(fx["views"]), stats)
+    assert ll.shape == (fx["gt"].shape[0], S - 1) and ll.dtype == torch.float64
+    xo = T(fx["gt"])
+    for n in range(S - 1):
+        gi = conv_inn[n]
+        axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+        zc = torch.zeros(xo.shape[0], xo.shape[1] // 2, xo.shape[2], xo.shape[3])
+        (zr, lowr), jr = O.flow_step({k: v.detach().cpu() for k, v in gi.state_dict().items()}, xo, [zc, zc], False, axes)
+        assert_close(ll[:, n], O.step_log_likelihood(zr, jr, lowr[0].numel()), TOL, f"step LL {n}")
+        xo = lowr
+    one = CWFA.step_log_likelihoods(conv_inn, cond_nets, args, cu(fx["gt"])[:1].clone(), cu(fx["views"])[:1], stats)
+    l1 = CWFA.evaluate_INN_forward(conv_inn, cond_nets, args, [args] * S, cu(fx["gt"])[:1].clone(), cu(fx["views"])[:1], stats)[0]
+    for n in range(S - 1):
+        assert abs(float(one[0, n]) + float(l1[n])) <= 1e-5 * abs(float(l1[n]))
+    assert_close(one[0], ll[0], 1e-6, "score independent of the batch it is computed in")
+    flags = CWFA.detect_ood(ll, 0, float(ll[:, 0].median()))
+    assert flags.dtype == torch.bool and flags.shape == (ll.shape[0],)
     # NLL of CWFA.py:978 through the shard-sum form, single process
     x = cu(fx["gt"])
     cz = [torch.zeros(x.shape[0], 8, *x.shape[2:], device="cuda")] * 2

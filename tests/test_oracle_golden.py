@@ -174,6 +174,10 @@ def test_pipeline_and_nll():
         nll = O.nll_from_terms(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], numel)
         ref = float((0.5 * torch.norm(z) ** 2 - jac.mean()) / numel)
         assert abs(nll - ref) <= 1e-5 * abs(ref)
+        # per-sample log-likelihoods (the OOD score) sum back to the reference's batch quantities
+        ll = O.step_log_likelihood(z, jac, low[0].numel())
+        want = numel * (fx["prior"][n] - x.shape[0] * fx["logjac"][n])
+        assert abs(float(-(ll * low[0].numel()).sum()) - want) <= 1e-5 * abs(want)
         x = low
 
 
