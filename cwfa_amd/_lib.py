@@ -27,6 +27,11 @@ class Chain(C.Structure):
     _fields_ = [("n_stages", C.c_int), ("stage", AffineStage * CHAIN_MAX)]
 
 
+class ChainGrads(C.Structure):
+    _fields_ = [("ds", c_f32p * CHAIN_MAX), ("dt", c_f32p * CHAIN_MAX), ("ds_bs", C.c_int64 * CHAIN_MAX),
+                ("dt_bs", C.c_int64 * CHAIN_MAX)]
+
+
 class ConvOpts(C.Structure):
     _fields_ = [("bias", c_f32p), ("act", C.c_int), ("prelu_alpha", c_f32p), ("residual", c_f32p), ("res_bs", C.c_int64),
                 ("act2", C.c_int), ("in_scale", c_f32p), ("in_shift", c_f32p), ("in_affine_bs", C.c_int), ("in_add", c_f32p),
@@ -63,6 +68,10 @@ SIGNATURES = {
     "cwfa_scale_channels_f32": (i, [p, p, p, i, i, i64, p]),
     "cwfa_axpby_f32": (i, [p, p, f, f, p, i64, p]),
     "cwfa_bn_running_update_f32": (i, [p, C.c_double, f, p, p, p, i, p]),
+    "cwfa_chain_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), p, p, i, i, i, i, i64, i64, i64, f, f, p]),
+    "cwfa_conv2d_wgrad_workspace_bytes": (i64, [i, i, i, i, i, i]),
+    "cwfa_conv2d_wgrad_f32": (i, [p, p, p, p, i, i, i, i, i, i, i64, i64, f, p]),
+    "cwfa_elu_bwd_f32": (i, [p, p, p, p, i, i64, i64, i64, i64, i64, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),

@@ -620,6 +620,64 @@ __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(const float* __rest
 }
 
 // rows variant usable?  (LDS budget, grid limits)
+// Backward of  L = gscale * 0.5 * sum z^2  -  ldscale * sum_b logdet_b  (CWFA.py:970-978: gscale = 1/numel,
+// ldscale = 1/(B*numel)) through a whole forward chain in ONE launch and without stored activations: the flow is
+// invertible, so the thread that owns a latent position walks the stages backwards, recovering each stage's input from
+// its output, u = (v - t) * exp(-s), while it carries the gradient g:
+//     dL/dt = g,   dL/ds = g * (v - t) - ldscale,   g <- g * exp(s),   position <- gather_k(position).
+// The gathers are bijections, so every (stage, position) pair is visited by exactly one thread: plain stores.
+__device__ __forceinline__ float soft_clamp_grad(float a, int kind, float clamp) {      // d soft_clamp / d a
+    switch (kind) {
+        case CWFA_CLAMP_ATAN: return clamp * 0.636f / (1.f + a * a);
+        case CWFA_CLAMP_TANH: {
+            const float th = tanhf(a);
+            return clamp * (1.f - th * th);
+        }
+        case CWFA_CLAMP_SIGMOID: {
+            const float sg = 1.f / (1.f + expf(-a));
+            return clamp * 2.f * sg * (1.f - sg);
+        }
+        default: return clamp;
+    }
+}
+
+__global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gz, cwfa_chain ch,
+                                                        cwfa_chain_grads gr, const int64_t* __restrict__ final_perm,
+                                                        float* __restrict__ gv0, int C, int H, int W, int64_t z_bs,
+                                                        int64_t gz_bs, int64_t gv0_bs, float gscale, float ldscale) {
+    const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    Pos p{(int)(i / HW), (int)((i / W) % H), (int)(i % W)};
+    float v = z[b * z_bs + i];
+    float g = (gz ? gz[b * gz_bs + i] : 0.f) + gscale * v;
+    p = gather_pos(p, final_perm, 1);
+#pragma unroll
+    for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k) {
+        if (k < ch.n_stages) {
+            const cwfa_affine_stage& st = ch.stage[k];
+            const int64_t off = lin(p, H, W);
+            float s, t;
+            stage_st(st, b, off, s, t);
+            const float e = v - t;
+            if (gr.ds[k]) {
+                const float a = st.s_raw[b * st.s_bs + off] * st.pre_scale;
+                gr.ds[k][b * gr.ds_bs[k] + off] = (g * e - ldscale) * soft_clamp_grad(a, st.clamp_kind, st.clamp) * st.pre_scale;
+            }
+            if (gr.dt[k]) gr.dt[k][b * gr.dt_bs[k] + off] = st.t_neg_div_sqrt2 ? (-g) / CWFA_SQRT2_F : g * st.pre_scale;
+            v = e * expf(-s);
+            g = g * expf(s);
+            p = gather_pos(p, st.perm, st.perm_axis);
+        }
+    }
+    if (gv0) gv0[b * gv0_bs + lin(p, H, W)] = g;
+}
+
+extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
+                                  const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
+                                  int64_t gv0_bs, float gscale, float ldscale, void* stream);
+
 static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds) {
     *lds = (size_t)(2 * ch->n_stages + 1) * W * sizeof(float);
     return *lds <= 60 * 1024 && C <= 65535 && B <= 65535 && W >= 64;
@@ -750,5 +808,24 @@ extern "C" int cwfa_extract_views_f32(const float* image, const int* coords_yx, 
     hipLaunchKernelGGL(extract_views_kernel, dim3(per < 256 ? per : 256, nviews, B), dim3(256), 0, (hipStream_t)stream, image,
                        coords_yx, views, Hs, Ws, nviews, sh, sw, mean, stdv, image_bs);
     CWFA_LAUNCH_CHECK("cwfa_extract_views_f32");
+    return CWFA_OK;
+}
+
+static int check_chain(const char* name, const cwfa_chain* ch);
+extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
+                                  const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
+                                  int64_t gv0_bs, float gscale, float ldscale, void* stream) {
+    CWFA_REQUIRE(z && grads, CWFA_E_INVAL, "cwfa_chain_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_bwd_f32: bad shape");
+    int rc = check_chain("cwfa_chain_bwd_f32", ch);
+    if (rc) return rc;
+    for (int k = 0; k < ch->n_stages; ++k)
+        CWFA_REQUIRE(!grads->ds[k] || ch->stage[k].s_raw, CWFA_E_INVAL, "cwfa_chain_bwd_f32: stage %d has no s but a ds buffer", k);
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(chain_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, gz, *ch, *grads, final_perm, gv0, C, H, W, z_bs,
+                       gz_bs, gv0_bs, gscale, ldscale);
+    CWFA_LAUNCH_CHECK("cwfa_chain_bwd_f32");
     return CWFA_OK;
 }

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -215,6 +215,33 @@ def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
     return z, low
 
 
+def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=None, want_input_grad=False):
+    """Backward of L = gscale*0.5*sum z^2 - ldscale*sum logdet (+ <gz, z>) through the chain that produced ``z``
+    (``chain_fwd`` with the same ``stages`` / ``final_perm``).  ``grads[k] = (ds_raw_k, dt_k)``: preallocated
+    [B,C,H,W] views (contiguous planes) or None.  Returns dL/d(detail band) if ``want_input_grad``."""
+    L = _lib.lib()
+    z, zbs = planes(z, "z")
+    B, Cc, H, W = z.shape
+    ch, keep = _chain(stages)
+    gr = _lib.ChainGrads()
+    for k, (ds, dt) in enumerate(grads):
+        for name, t in (("ds", ds), ("dt", dt)):
+            if t is None:
+                continue
+            t2, bs = planes(t, name)
+            if t2.data_ptr() != t.data_ptr() or tuple(t.shape) != (B, Cc, H, W):
+                raise ValueError(f"chain_bwd: {name}[{k}] must be a [B,C,H,W] view with contiguous planes")
+            getattr(gr, name)[k] = t.data_ptr()
+            getattr(gr, name + "_bs")[k] = bs
+    gzbs = 0
+    if gz is not None:
+        gz, gzbs = planes(gz, "gz")
+    gv0 = torch.empty((B, Cc, H, W), dtype=torch.float32, device=z.device) if want_input_grad else None
+    check(L.cwfa_chain_bwd_f32(_p(z), _p(gz), C.byref(ch), C.byref(gr), _p(_idx(final_perm)), _p(gv0), B, Cc, H, W, zbs, gzbs,
+                               Cc * H * W, float(gscale), float(ldscale), _stream()), "chain_bwd")
+    return gv0
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
@@ -379,6 +406,54 @@ def subnet_layer(x, pc3, b3, panel1, b1):
     if rec is not None and rec.want(key):
         e1.record()
         rec.add(key, e0, e1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ backward of the sub-networks
+_wgrad_ws = {}
+
+
+def conv2d_wgrad(x, dy, ks, out=None, accumulate=False):
+    """dW [Cout,Cin,ks,ks] of a stride-1 'same' convolution y = conv(x, W): sum over batch and pixels of dy (x) shifted x.
+    With ``out`` and ``accumulate`` the result is added to ``out`` (a .grad buffer)."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    dy, dbs = planes(dy, "dy")
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != (B, Cout, H, W):
+        raise ValueError(f"conv2d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
+        accumulate = False
+    elif tuple(out.shape) != (Cout, Cin, ks, ks) or not out.is_contiguous():
+        raise ValueError("conv2d_wgrad: `out` must be a contiguous [Cout,Cin,ks,ks] tensor")
+    nbytes = L.cwfa_conv2d_wgrad_workspace_bytes(B, Cin, H, W, Cout, ks)
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _wgrad_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    check(L.cwfa_conv2d_wgrad_f32(_p(x), _p(dy), _p(out), _p(ws), B, Cin, H, W, Cout, ks, xbs, dbs, 1.0 if accumulate else 0.0,
+                                  _stream()), "conv2d_wgrad")
+    return out
+
+
+def elu_bwd(g, a, add=None, out=None):
+    """g * ELU'(q) from the activation output a = ELU(q) (+ add); may run in place on g."""
+    L = _lib.lib()
+    g, gbs = planes(g, "g")
+    a, abs_ = planes(a, "a")
+    B = g.shape[0]
+    n = g[0].numel()
+    addbs = 0
+    if add is not None:
+        add, addbs = planes(add, "add")
+    if out is None:
+        out = torch.empty(tuple(g.shape), dtype=torch.float32, device=g.device)
+    o2, obs = planes(out, "out")
+    if o2.data_ptr() != out.data_ptr():
+        raise ValueError("elu_bwd: `out` must have contiguous planes")
+    check(L.cwfa_elu_bwd_f32(_p(g), _p(a), _p(add), _p(out), B, n, gbs, abs_, addbs, obs, _stream()), "elu_bwd")
     return out
 
 

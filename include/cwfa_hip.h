@@ -273,6 +273,39 @@ int cwfa_subnet_layer_split_f32(const float* x, const void* w3_split, const floa
 int cwfa_extract_views_f32(const float* image, const int* coords_yx, float* views, int B, int Hs, int Ws, int nviews, int sh,
                            int sw, float mean, float stdv, int64_t image_bs, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the flow-step training loss (what torch autograd does under
+ * `scaler.scale(full_loss).backward()` CWFA.py:1002-1006 for the NLL term of CWFA.py:966-978)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Gradient buffers of a chain: for stage k (same order as the cwfa_chain handed to cwfa_chain_fwd_f32) ds[k] receives
+ * dL/d s_raw and dt[k] dL/d t (the tensors the sub-network produced), NULL = not wanted. */
+typedef struct {
+    float* ds[CWFA_CHAIN_MAX];
+    float* dt[CWFA_CHAIN_MAX];
+    int64_t ds_bs[CWFA_CHAIN_MAX], dt_bs[CWFA_CHAIN_MAX];
+} cwfa_chain_grads;
+
+/* L = gscale * 0.5 * sum z^2 - ldscale * sum_b logdet_b (+ <gz, z> for an upstream gradient gz, nullable), z the output
+ * of cwfa_chain_fwd_f32 with the same chain / final_perm.  No stored activations: every stage input is recomputed by
+ * inverting the stage.  gv0 (nullable) receives dL/d(detail band entering the chain). */
+int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
+                       const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
+                       int64_t gv0_bs, float gscale, float ldscale, void* stream);
+
+/* Weight gradient of a stride-1, zero-padded ("same") convolution, ks = 1 or 3, on the fp32 matrix cores:
+ *   dw[co][ci][ky][kx] = beta * dw + sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-ks/2][x+kx-ks/2]     (torch layout)
+ * x [B,Cin,H,W] (batch stride x_bs), dy [B,Cout,H,W] (dy_bs).  workspace: cwfa_conv2d_wgrad_workspace_bytes() bytes
+ * (per-worker partial filter banks, summed in a fixed order: the result is deterministic). */
+int64_t cwfa_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int ks);
+int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout,
+                          int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream);
+
+/* ELU backward from the layer output a = ELU(q):  y = g * (a > 0 ? 1 : a + 1) (+ add, nullable).  n elements per sample
+ * (multiple of 4), batch strides in elements. */
+int cwfa_elu_bwd_f32(const float* g, const float* a, const float* add, float* y, int B, int64_t n, int64_t g_bs, int64_t a_bs,
+                     int64_t add_bs, int64_t y_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""GPU (MI355X): the backward kernels of the flow-step training loss against torch autograd in
+float64 on the CPU -- the thing `full_loss.backward()` (CWFA.py:1002-1006) runs in the reference.
+Tolerance: max|d|/max|ref| and L2-relative <= 1e-4 (fp32 sums over up to 2.6e5 pixels; observed ~1e-6)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cwfa_amd import _lib
+    _lib.lib()
+    yield
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cfg", [  # (B, Cin, Cout, H, W, ks)
+    (1, 64, 64, 64, 64, 3), (2, 64, 64, 37, 45, 3), (1, 58, 64, 33, 31, 1), (2, 64, 24, 20, 70, 3), (1, 96, 96, 17, 33, 3),
+    (1, 64, 64, 40, 40, 1), (3, 7, 5, 9, 11, 3), (1, 130, 70, 8, 8, 1), (1, 64, 64, 1, 1, 3), (1, 64, 64, 128, 128, 3)])
+def test_conv_weight_gradient_vs_autograd(cfg):
+    from cwfa_amd import ops
+    B, Cin, Cout, H, W, ks = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, padding=ks // 2) * dy.double()).sum().backward()
+    got = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks)
+    assert_close(got, w.grad, TOL, f"dW {cfg}")
+    # accumulate into an existing gradient buffer; channel-sliced (strided-batch) operands
+    base = torch.randn(Cout, Cin, ks, ks, generator=g)
+    xb = torch.randn(B, Cin + 3, H, W, generator=g)
+    xb[:, 2:2 + Cin] = x
+    acc = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), ks, out=base.cuda().clone(), accumulate=True)
+    assert_close(acc, w.grad + base.double(), TOL, f"dW accumulate {cfg}")
+    # deterministic: the partial sums are combined in a fixed order
+    assert torch.equal(got, ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks))
+
+
+def test_elu_backward():
+    from cwfa_amd import ops
+    g0 = torch.Generator().manual_seed(3)
+    q = torch.randn(2, 6, 10, 14, generator=g0, dtype=torch.float64, requires_grad=True)
+    a = F.elu(q)
+    gup = torch.randn(2, 6, 10, 14, generator=g0)
+    add = torch.randn(2, 6, 10, 14, generator=g0)
+    a.backward(gup.double())
+    got = ops.elu_bwd(gup.cuda(), a.detach().float().cuda())
+    assert_close(got, q.grad, 1e-6, "elu backward")
+    got = ops.elu_bwd(gup.cuda(), a.detach().float().cuda(), add=add.cuda())
+    assert_close(got, q.grad + add.double(), 1e-6, "elu backward + add")
+
+
+def _torch_chain(hi, stages, final_perm):
+    """float64 restatement of cwfa_chain_fwd_f32's stage loop; returns (z, sum of s per sample)."""
+    v, logdet = hi, 0.0
+    for st in stages:
+        if st["perm"] is not None:
+            v = v.index_select(st["axis"], st["perm"])
+        s = st["clamp"] * 0.636 * torch.atan(st["s_raw"] * st["pre"]) if st["s_raw"] is not None else None
+        if st["t"] is not None:
+            t = -st["t"] / math.sqrt(2.0) if st["neg"] else st["t"] * st["pre"]
+        else:
+            t = 0.0
+        if s is not None:
+            v = torch.exp(s) * v + t
+            logdet = logdet + s.flatten(1).sum(1)
+        else:
+            v = v + t
+    return (v if final_perm is None else v.index_select(1, final_perm)), logdet
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 12), (1, 12, 16, 16), (3, 3, 5, 7)])
+def test_chain_backward_vs_autograd(shape):
+    """Five stages with channel / row / column gathers, the `_first` pass-through stage (t = -mean/sqrt 2) and a trailing
+    channel permutation -- the step graph of networks.py:305-366 -- against float64 autograd of the same chain."""
+    from cwfa_amd import ops
+    B, Cc, H, W = shape
+    g0 = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, 2 * Cc, H, W, generator=g0)
+    axes = [None, 1, 2, 3, 1]
+    ref_stages, stages, leaves = [], [], []
+    for k, ax in enumerate(axes):
+        s_raw = torch.randn(B, Cc, H, W, generator=g0)
+        t = torch.randn(B, Cc, H, W, generator=g0)
+        perm = None if ax is None else torch.randperm([0, Cc, H, W][ax], generator=g0)
+        neg = k == 0
+        sr, tr = s_raw.double().requires_grad_(), t.double().requires_grad_()
+        leaves.append((sr, tr))
+        ref_stages.append({"s_raw": sr, "t": tr, "perm": perm, "axis": ax, "clamp": 2.0, "pre": 1.0, "neg": neg})
+        stages.append(ops.stage(s_raw.cuda(), t.cuda(), "ATAN", 2.0, t_neg_div_sqrt2=neg, perm=None if perm is None else perm.cuda(),
+                                axis=ax or 1))
+    final_perm = torch.randperm(Cc, generator=g0)
+    xd = x.double()
+    hi = ((xd[:, 0::2] - xd[:, 1::2]) / math.sqrt(2.0)).requires_grad_()
+    zr, ld = _torch_chain(hi, ref_stages, final_perm)
+    numel = zr.numel()
+    gscale, ldscale = 1.0 / numel, 1.0 / (B * numel)
+    loss = gscale * 0.5 * (zr ** 2).sum() - ldscale * ld.sum()
+    loss.backward()
+    z, low = ops.chain_fwd(x.cuda(), stages, final_perm.cuda())
+    assert_close(z, zr.detach(), 1e-5, "chain forward")
+    grads = [(torch.empty(B, Cc, H, W, device="cuda"), torch.empty(B, Cc, H, W, device="cuda")) for _ in axes]
+    gv0 = ops.chain_bwd(z, stages, grads, final_perm.cuda(), gscale, ldscale, want_input_grad=True)
+    for k, ((ds, dt), (sr, tr)) in enumerate(zip(grads, leaves)):
+        assert_close(ds, sr.grad, TOL, f"ds_raw stage {k}")
+        assert_close(dt, tr.grad, TOL, f"dt stage {k}")
+    assert_close(gv0, hi.grad, TOL, "gradient of the detail band")
