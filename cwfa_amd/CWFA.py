@@ -194,13 +194,14 @@ def inverse_pass(conv_inn, cond_nets, cond_input, mean_vols_cache, low=None, tem
 
 def nll_step(graph, x, c, group=None):
     """Training-time NLL of one step, CWFA.py:966-978:  (0.5*||Z0||^2 - mean_b logdet) / numel(batch volume),
-    with the norm taken over the WHOLE (global) batch.  With a process group the three shard sums are all-reduced
+    with the norm taken over the WHOLE (global) batch.  The divisor is ``upsampled_vol.numel()`` = B*D_n*H*W, the step's
+    full-depth volume (CWFA.py:911,978) -- twice ``Z[-1].numel()``, which ``evaluate_INN_forward`` divides by (:186).  With a process group the three shard sums are all-reduced
     (RCCL over xGMI on MI355X: one float64[3] message) and every rank returns the identical global value."""
     Z, logdet, sumsq = nll_terms(graph, x, c)
     terms = torch.stack([sumsq[0], logdet.to(torch.float64).sum(),
                          torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)])
     terms = allreduce_nll(terms, group)
-    numel_total = terms[2] * (Z[1][0].numel() if len(Z) > 1 else Z[0][0].numel())
+    numel_total = terms[2] * x[0].numel()      # `upsampled_vol.numel()`: the step's whole input volume (CWFA.py:911,978)
     nll = (0.5 * terms[0] - terms[1] / terms[2]) / numel_total
     return nll, Z, logdet
 

@@ -316,8 +316,9 @@ class _CatStepPlan:
         self.graph, self.chain = graph, chain
         self.flow_out_idx, self.low_out_idx = flow_out_idx, low_out_idx
 
-    def _stages(self, cond_of, rev):
-        """Stage list in execution order; every stage = (input gather, affine)."""
+    def _stages(self, cond_of, rev, coefficients=None):
+        """Stage list in execution order; every stage = (input gather, affine).  ``coefficients(module, conditions)``
+        -> (s_raw, t, t_neg_div_sqrt2) replaces the block's own sub-network call (the training path keeps a tape)."""
         stages, pending = [], None
         seq = list(reversed(self.chain)) if rev else self.chain
         for kind, obj in seq:
@@ -328,7 +329,11 @@ class _CatStepPlan:
             else:
                 c = [cond_of[cn] for cn in obj.conditions]
                 perm, axis = pending if pending is not None else (None, 1)
-                stages.append(obj.module.stage(c, perm=perm, axis=axis))
+                if coefficients is None:
+                    stages.append(obj.module.stage(c, perm=perm, axis=axis))
+                else:
+                    s_raw, t, tneg = coefficients(obj.module, c)
+                    stages.append(obj.module._stage(s_raw, t, t_neg_div_sqrt2=tneg, perm=perm, axis=axis))
                 pending = None
         return stages, pending
 

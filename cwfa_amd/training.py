@@ -1,0 +1,241 @@
+"""Backward of the flow-step NLL and the data-parallel gradient exchange.
+
+Reference: the training branch of ``run_CWFA`` -- ``Z, log_jac_det = conv_inn[n_net](curr_gt, c=cond_processed)``,
+``curr_LL_loss = (0.5*||Z0||^2 - log_jac_det.mean()) / numel`` (CWFA.py:966-978) followed by
+``scaler.scale(full_loss).backward()`` and the optimiser step (CWFA.py:1002-1027).  There torch autograd records every
+stock op; here the step's structure is used instead:
+
+* the coupling coefficients of a CAT step depend on the conditions only, so the forward is "evaluate each block's
+  sub-network (kept unfused, its seven post-activation maps saved), then ONE fused chain launch";
+* the flow is invertible, so the chain's backward needs no saved activations (``ops.chain_bwd``: one launch that walks
+  the stages backwards from z, recomputing every stage input by inverting the stage);
+* a sub-network's backward is 8 data-gradient convolutions on the forward MFMA kernels (filters transposed + flipped),
+  8 weight-gradient GEMMs (``ops.conv2d_wgrad``), ELU-backward passes and per-channel sums for the biases.
+
+Multi-GPU (one process per GPU, batch sharded as in SURVEY.md 8(e)): the loss is defined on the GLOBAL batch, so every
+rank scales its local gradient by the global 1/numel and the ranks' gradients are SUMMED -- ``allreduce_gradients``
+packs them into a few large flat buckets (default 64 MiB: the flow parameters of one step are 13.7 MB, so one message)
+and issues one all-reduce per bucket (RCCL over xGMI on MI355X; gloo in the CPU test).
+
+Scope of this slice: gradients of the flow step's own parameters (the reference's ``optimizer``) and dL/d(conditions);
+the condition networks' backward (``optimizer_cond``: Conv3d / LRNN) is not built yet.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "allreduce_gradients", "sgd_step"]
+
+
+class _Tape:
+    """Saved post-activation maps of one sub-network evaluation."""
+    __slots__ = ("net", "conv_in", "conv_out", "u", "b", "h")
+
+    def __init__(self, net, conv_in, conv_out, u):
+        self.net, self.conv_in, self.conv_out, self.u = net, conv_in, conv_out, u
+        self.b, self.h = [], []
+
+
+def _layers(net):
+    return (net.block2, net.block4, net.block6)
+
+
+def subnet_forward_train(net, u, conv_in, conv_out):
+    """``wavelet_flow_subnetwork._stack`` (networks.py:641-667) with every layer's output kept for the backward:
+    b0 = conv_in(u);  h_i = ELU(conv3x3(b_{i-1}));  b_i = ELU(conv1x1(h_i) + b_{i-1});  a = conv_out(b_3)."""
+    P = net._packed.get
+    tape = _Tape(net, conv_in, conv_out, u)
+    b = ops.conv2d(u, P(conv_in), bias=conv_in.bias)
+    tape.b.append(b)
+    for blk in _layers(net):
+        h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")
+        b = ops.conv2d(h, P(blk[2]), bias=blk[2].bias, residual=b, act2="elu")
+        tape.h.append(h)
+        tape.b.append(b)
+    return ops.conv2d(b, P(conv_out), bias=conv_out.bias), tape
+
+
+_packT_cache = {}
+
+
+def _packT(conv):
+    """Filter bank of the data-gradient convolution: W^T[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx], in kernel layout."""
+    w = conv.weight
+    key = id(conv)
+    hit = _packT_cache.get(key)
+    if hit is None or hit[1] != w._version or hit[2] != w.data_ptr() or hit[0].epoch != ops.pack_epoch():
+        wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()
+        hit = _packT_cache[key] = (ops.pack_conv_weight(wt), w._version, w.data_ptr())
+    return hit[0]
+
+
+def _acc_grad(param, g):
+    if param.grad is None:
+        param.grad = g
+    else:
+        param.grad.add_(g)
+
+
+def _conv_param_grads(conv, x, dy):
+    """Accumulate dL/dW, dL/db of ``y = conv(x)`` into conv.weight.grad / conv.bias.grad."""
+    ks = conv.kernel_size[0]
+    w = conv.weight
+    if w.grad is None:
+        w.grad = ops.conv2d_wgrad(x, dy, ks)
+    else:
+        ops.conv2d_wgrad(x, dy, ks, out=w.grad, accumulate=True)
+    if conv.bias is not None:
+        _acc_grad(conv.bias, ops.channel_stats(dy).view(-1, 2)[:, 0].to(torch.float32))
+
+
+def subnet_backward(tape, g_a, want_input_grad=False):
+    """Backward of ``subnet_forward_train``: accumulates the .grad of its eight convolutions from dL/da ``g_a``
+    (overwritten as scratch) and returns dL/du if wanted."""
+    net = tape.net
+    _conv_param_grads(tape.conv_out, tape.b[3], g_a)
+    g_b = ops.conv2d(g_a, _packT(tape.conv_out))
+    for i in (2, 1, 0):
+        blk = _layers(net)[i]
+        b_in, h, b_out = tape.b[i], tape.h[i], tape.b[i + 1]
+        g_r = ops.elu_bwd(g_b, b_out, out=g_b)                       # through the trailing ELU; also the residual branch
+        _conv_param_grads(blk[2], h, g_r)
+        g_q = ops.conv2d(g_r, _packT(blk[2]))
+        ops.elu_bwd(g_q, h, out=g_q)
+        _conv_param_grads(blk[0], b_in, g_q)
+        g_b = ops.conv2d(g_q, _packT(blk[0]), residual=g_r)
+    _conv_param_grads(tape.conv_in, tape.u, g_b)
+    return ops.conv2d(g_b, _packT(tape.conv_in)) if want_input_grad else None
+
+
+def nll_backward(graph, x, c, group=None, want_cond_grads=False):
+    """One training-step forward + backward of a CAT flow step on this rank's batch shard.
+
+    Returns ``(nll, Z, cond_grads)``: the global-batch NLL of CWFA.py:978 (identical on every rank), the forward
+    outputs, and dL/d(condition) per condition tensor (or None).  Parameter gradients are accumulated into ``.grad``
+    (LOCAL contributions: call ``allreduce_gradients`` before the optimiser step when running on several ranks)."""
+    from .CWFA import allreduce_nll
+    plan = getattr(graph, "_plan", None)
+    if plan is None:
+        raise NotImplementedError("nll_backward: only conditional-affine (CAT) steps lowered to a chain plan are built")
+    cond_of = dict(zip(graph.condition_nodes, c))
+    tapes = []
+
+    def coefficients(module, parts):
+        net, n_s = module.subnet, module.channels
+        if not hasattr(net, "block12"):
+            raise NotImplementedError("nll_backward: sub-network type without a HIP backward")
+        if net.normal:
+            u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+            a, tape = subnet_forward_train(net, u, net.block12, net.block72[1])
+            tapes.append((tape, a, parts, "normal"))
+            return a[:, :n_s], a[:, n_s:], False
+        n = net.c_in // 2
+        if not (len(parts) == 2 and parts[1].shape[1] == n and net.c_out // 2 == n_s):
+            raise NotImplementedError("nll_backward: `_first` sub-network with an unexpected condition layout")
+        mean, om = parts
+        a, tape = subnet_forward_train(net, om, net.block1, net.block7[1])
+        tapes.append((tape, a, parts, "first"))
+        return a, mean, True
+
+    stages, pending = plan._stages(cond_of, False, coefficients=coefficients)
+    final_perm = None
+    if pending is not None:
+        if pending[1] == 1:
+            final_perm = pending[0]
+        else:
+            stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
+    B = x.shape[0]
+    logdet = torch.zeros(B, dtype=torch.float64, device=x.device)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=x.device)
+    z, low = ops.chain_fwd(x, stages, final_perm, logdet=logdet, sumsq=sumsq)
+    terms = torch.stack([sumsq[0], logdet.sum(), torch.tensor(float(B), dtype=torch.float64, device=x.device)])
+    terms = allreduce_nll(terms, group)
+    Bg = float(terms[2])
+    numel_total = Bg * x[0].numel()             # `upsampled_vol.numel()`: the step's whole input volume (CWFA.py:911,978)
+    nll = (0.5 * terms[0] - terms[1] / terms[2]) / numel_total
+
+    # backward: chain (one launch), then every block's sub-network
+    Cc, H, W = z.shape[1:]
+    grads, holders = [], []
+    it = iter(tapes)
+    for st, _keep in stages:
+        if not st.s_raw and not st.t:
+            grads.append((None, None))
+            continue
+        tape, a, parts, kind = next(it)
+        if kind == "normal":
+            g_a = torch.empty_like(a)
+            grads.append((g_a[:, :Cc], g_a[:, Cc:]))
+            holders.append((tape, g_a, None, parts))
+        else:
+            g_a = torch.empty_like(a)
+            g_mean = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device) if want_cond_grads else None
+            grads.append((g_a, g_mean))
+            holders.append((tape, g_a, g_mean, parts))
+    ops.chain_bwd(z, stages, grads, final_perm, gscale=1.0 / numel_total, ldscale=1.0 / (Bg * numel_total))
+    cond_grads = None
+    if want_cond_grads:
+        cond_grads = {id(t): None for t in c}
+    for tape, g_a, g_mean, parts in holders:
+        g_u = subnet_backward(tape, g_a, want_input_grad=want_cond_grads)
+        if not want_cond_grads:
+            continue
+        if g_mean is not None:                           # `_first`: parts = (mean, omega)
+            pieces = [g_mean, g_u]
+        else:
+            pieces, c0 = [], 0
+            for t in parts:
+                pieces.append(g_u[:, c0:c0 + t.shape[1]])
+                c0 += t.shape[1]
+        for t, g in zip(parts, pieces):
+            cur = cond_grads.get(id(t))
+            cond_grads[id(t)] = g.contiguous() if cur is None else ops.axpby(g, 1.0, cur, 1.0)
+    if want_cond_grads:
+        cond_grads = [cond_grads[id(t)] for t in c]
+    return nll, (z, low), cond_grads
+
+
+def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+    """SUM the ranks' gradients (the loss is defined on the global batch, see the module docstring).  Gradients are
+    packed into flat buckets of at most ``bucket_bytes`` in parameter order, one all-reduce per bucket, and copied back;
+    every rank must pass the same parameter list.  No-op without an initialised process group or with one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return 0
+    params = [p for p in params if p.requires_grad]
+    n_buckets, i = 0, 0
+    while i < len(params):
+        j, size = i, 0
+        while j < len(params) and (j == i or size + params[j].numel() * 4 <= bucket_bytes):
+            size += params[j].numel() * 4
+            j += 1
+        chunk = params[i:j]
+        flat = torch.zeros(size // 4, dtype=torch.float32, device=chunk[0].device)
+        off = 0
+        for p in chunk:                                  # a parameter without a local gradient contributes zeros
+            if p.grad is not None:
+                flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for p in chunk:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+        n_buckets += 1
+        i = j
+    return n_buckets
+
+
+def sgd_step(params, lr):
+    """Plain gradient step (enough to show the loss going down in tests; the reference trains with torch optimisers,
+    which work on these parameters / .grad tensors unchanged)."""
+    with torch.no_grad():
+        for p in params:
+            if p.grad is not None:
+                p.add_(p.grad, alpha=-lr)

@@ -23,6 +23,7 @@ Fixture index:
   g10_pipeline      2-step inverse pipeline + evaluate_INN_forward (CWFA.py:134-196,865-924)
   g11_unet_*, g11_convnext, g11_attention, g11_lrnn_small, g11_lrnn_full
   g12_extract_views_*   XLFMDatasetFull.extract_views (needs only torch: imported from the reference file directly)
+  g13_step_grad_*       autograd gradients of the training NLL of one CAT step (CWFA.py:966-978,1002-1006)
 """
 import os
 import sys
@@ -363,9 +364,52 @@ def gen_extract_views():
              views=npy(views), normalized=npy((views - mean) / std), mean=np.float32(mean), std=np.float32(std))
 
 
+def gen_step_grad():
+    """g13: gradients of the training NLL (CWFA.py:966-978) of one CAT step w.r.t. every parameter and both
+    conditions, from the reference's own graph + torch autograd -- what `full_loss.backward()` (CWFA.py:1002-1006)
+    produces for the log-likelihood term.  Steps built as run_CWFA does (CWFA.py:498-510), small channel counts."""
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    import torch
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(1313)
+    S, D, H, W = 3, 16, 12, 16
+    for ix, n_ch in ((0, 8), (1, 8), (0, 64)):
+        torch.manual_seed(300 + ix)
+        np.random.seed(7)
+        networks.networks_n_chans = n_ch
+        Cn = D // 2 ** (ix + 1)
+        cond_net, inns = networks.conditional_wavelet_flow(
+            [D, H, W], [1, 29, H, W], networks.wavelet_flow_subnetwork2D,
+            lambda: networks.cond_network(29, Cn, ix + 1, S, [], 4),
+            n_internal_ch=n_ch, n_down_steps=ix + 1, use_permutations=True, block_type="CAT", n_blocks=4)
+        inn = inns[ix].train()
+        with torch.no_grad():
+            for p in inn.parameters():
+                if p.requires_grad and p.dtype == torch.float32:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        meta = {}
+        for i, mdl in enumerate(inn.module_list):
+            if type(mdl).__name__ == "PermuteDim":
+                meta[f"meta/axis_{i}"] = np.int64(mdl.dims_to_permute[1])
+        Dn = D // 2 ** ix
+        B = 3
+        x = torch.randn(B, Dn, H, W, generator=g)
+        c = [torch.randn(B, Cn, H, W, generator=g).requires_grad_(), (0.3 * torch.randn(B, Cn, H, W, generator=g)).requires_grad_()]
+        Z, log_jac_det = inn(x, c=c)
+        loss = (0.5 * torch.norm(Z[0]) ** 2 - log_jac_det.mean()) / x.numel()      # upsampled_vol has x's shape (CWFA.py:911,978)
+        loss.backward()
+        grads = {"grad/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None}
+        dump(f"g13_step_grad_k{ix}_ch{n_ch}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z=npy(Z[0]), low=npy(Z[1]), loss=np.float64(loss.item()),
+             gc0=npy(c[0].grad), gc1=npy(c[1].grad), D=np.int64(D), H=np.int64(H), W=np.int64(W), ix=np.int64(ix), S=np.int64(S),
+             n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extract_views":
         gen_extract_views()
+    elif len(sys.argv) > 1 and sys.argv[1] == "step_grad":
+        gen_step_grad()
     else:
         main()
         gen_extract_views()
+        gen_step_grad()

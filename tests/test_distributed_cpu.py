@@ -34,10 +34,10 @@ def _worker(rank, world, port, q):
         (z, low), jac = O.flow_step(sd, x[lo:hi], [t[lo:hi] for t in c], False, axes)
         s, j, n = O.nll_terms(z, jac)
         terms = allreduce_nll(torch.tensor([s, j, float(n)], dtype=torch.float64))
-        nll = O.nll_from_terms(float(terms[0]), float(terms[1]), int(terms[2]), int(terms[2]) * low[0].numel())
+        nll = O.nll_from_terms(float(terms[0]), float(terms[1]), int(terms[2]), int(terms[2]) * x[0].numel())
         # single-process reference over the whole batch (CWFA.py:970-978)
         (zf, lowf), jf = O.flow_step(sd, x, c, False, axes)
-        ref = float((0.5 * torch.norm(zf) ** 2 - jf.mean()) / lowf.numel())
+        ref = float((0.5 * torch.norm(zf) ** 2 - jf.mean()) / x.numel())         # CWFA.py:978: / upsampled_vol.numel()
         q.put((rank, nll, ref, int(terms[2])))
     finally:
         dist.destroy_process_group()

@@ -114,3 +114,64 @@ def test_chain_backward_vs_autograd(shape):
         assert_close(ds, sr.grad, TOL, f"ds_raw stage {k}")
         assert_close(dt, tr.grad, TOL, f"dt stage {k}")
     assert_close(gv0, hi.grad, TOL, "gradient of the detail band")
+
+
+def _golden_step(name):
+    import numpy as np
+    from conftest import load_golden, sd_of
+    from cwfa_amd import networks as N
+    from test_host_logic import build_step
+    fx = load_golden(name)
+    ix, n_ch = int(fx["ix"]), int(fx["n_ch"])
+    keep = N.networks_n_chans
+    try:
+        _, g = build_step("CAT", ix, n_ch=n_ch)
+    finally:
+        N.networks_n_chans = keep
+    g.load_state_dict(sd_of(fx))
+    for i, m in enumerate(g.module_list):
+        if f"meta/axis_{i}" in fx:
+            assert int(m.axis) == int(fx[f"meta/axis_{i}"])
+    return fx, g.train().cuda()
+
+
+@pytest.mark.parametrize("name", ["g13_step_grad_k0_ch8", "g13_step_grad_k1_ch8", "g13_step_grad_k0_ch64"])
+def test_step_nll_backward_golden(name):
+    """Forward + backward of one CAT step's training NLL through the HIP path against the reference's own autograd
+    (fixture g13, generated by importing the reference: oracle/make_golden.py step_grad): loss, the gradient of every
+    parameter the loss reaches, and the gradients of both conditions."""
+    from cwfa_amd import training
+    fx, g = _golden_step(name)
+    x = torch.from_numpy(fx["x"]).cuda()
+    c = [torch.from_numpy(fx["c0"]).cuda(), torch.from_numpy(fx["c1"]).cuda()]
+    nll, (z, low), cg = training.nll_backward(g, x, c, want_cond_grads=True)
+    assert abs(float(nll) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    assert_close(z, fx["z"], TOL, "z")
+    want = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    got = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
+    assert set(got) == set(want), sorted(set(got) ^ set(want))[:6]
+    for k in sorted(want):
+        assert_close(got[k], want[k], TOL, k)
+    assert_close(cg[0], fx["gc0"], TOL, "d loss / d omega")
+    assert_close(cg[1], fx["gc1"], TOL, "d loss / d mean detail")
+    # a second backward accumulates, as torch's .grad does
+    training.nll_backward(g, x, c)
+    k0 = sorted(want)[0]
+    assert_close(dict(g.named_parameters())[k0].grad, 2 * torch.from_numpy(want[k0]), TOL, "accumulated gradient")
+
+
+def test_training_steps_reduce_the_nll():
+    """Three plain gradient steps on one batch lower the NLL (end-to-end sign / scale check of the backward)."""
+    from cwfa_amd import training
+    fx, g = _golden_step("g13_step_grad_k0_ch8")
+    x = torch.from_numpy(fx["x"]).cuda()
+    c = [torch.from_numpy(fx["c0"]).cuda(), torch.from_numpy(fx["c1"]).cuda()]
+    params = [p for p in g.parameters() if p.requires_grad]
+    hist = []
+    for _ in range(4):
+        for p in params:
+            p.grad = None
+        nll, _, _ = training.nll_backward(g, x, c)
+        hist.append(float(nll))
+        training.sgd_step(params, 0.05)
+    assert hist[-1] < hist[0] and all(b <= a + 1e-6 for a, b in zip(hist, hist[1:])), hist

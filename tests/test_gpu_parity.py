@@ -454,7 +454,7 @@ def test_pipeline_golden():
     x = cu(fx["gt"])
     cz = [torch.zeros(x.shape[0], 8, *x.shape[2:], device="cuda")] * 2
     nll, Z, jac = CWFA.nll_step(conv_inn[0], x, cz)
-    ref = (0.5 * torch.norm(Z[0]) ** 2 - jac.mean()) / Z[1].numel()
+    ref = (0.5 * torch.norm(Z[0]) ** 2 - jac.mean()) / x.numel()          # CWFA.py:978: / upsampled_vol.numel()
     assert abs(float(nll) - float(ref)) <= 1e-5 * abs(float(ref))
 
 
@@ -675,7 +675,7 @@ def test_full_size_forward_nll_vs_oracle():
     assert_close(Z[1], lowr, 2e-6, "low band")
     assert_close(logdet, ldr, TOL, "log-det")
     ss, sl, B = O.nll_terms(zr, ldr)
-    ref = O.nll_from_terms(ss, sl, B, lowr.numel())
+    ref = O.nll_from_terms(ss, sl, B, x.numel())
     assert abs(float(nll) - ref) <= 1e-5 * abs(ref)
 
 

@@ -171,8 +171,8 @@ def test_pipeline_and_nll():
         # shard-decomposed NLL equals the batch formula of CWFA.py:978
         t0 = O.nll_terms(z[:1], jac[:1])
         t1 = O.nll_terms(z[1:], jac[1:])
-        nll = O.nll_from_terms(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], numel)
-        ref = float((0.5 * torch.norm(z) ** 2 - jac.mean()) / numel)
+        nll = O.nll_from_terms(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], x.numel())
+        ref = float((0.5 * torch.norm(z) ** 2 - jac.mean()) / x.numel())       # CWFA.py:978: / upsampled_vol.numel()
         assert abs(nll - ref) <= 1e-5 * abs(ref)
         # per-sample log-likelihoods (the OOD score) sum back to the reference's batch quantities
         ll = O.step_log_likelihood(z, jac, low[0].numel())
@@ -205,3 +205,25 @@ def test_extract_views(name):
     img, coords, sub = T(fx["image"]), fx["coords"].tolist(), fx["sub"].tolist()
     assert np.array_equal(O.extract_views(img, coords, sub).numpy(), fx["views"])
     assert np.array_equal(O.extract_views(img, coords, sub, float(fx["mean"]), float(fx["std"])).numpy(), fx["normalized"])
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(GOLDEN + "/g13_*.npz")))
+def test_step_gradients_vs_reference_autograd(name):
+    """The oracle is plain differentiable torch: autograd through it must give the gradients the reference's own graph
+    gave for the training NLL of CWFA.py:966-978 (fixture g13: every parameter with a gradient, both conditions)."""
+    fx = load_golden(name)
+    sd = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point else v) for k, v in sd_of(fx).items()}
+    axes = {i: 1 for i in range(3, 12, 2)}
+    axes.update(_axes(fx))
+    x = T(fx["x"])
+    c = [T(fx["c0"]).requires_grad_(), T(fx["c1"]).requires_grad_()]
+    (z, low), jac = O.flow_step(sd, x, c, False, axes, "CAT")
+    loss = (0.5 * torch.norm(z) ** 2 - jac.mean()) / x.numel()
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    names = [k[len("grad/"):] for k in fx if k.startswith("grad/")]
+    assert len(names) == 80
+    for k in names:
+        assert_close(sd[k].grad, fx["grad/" + k], 1e-4, k)
+    assert_close(c[0].grad, fx["gc0"], 1e-4, "d loss / d omega")
+    assert_close(c[1].grad, fx["gc1"], 1e-4, "d loss / d mean detail")
