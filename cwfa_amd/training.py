@@ -205,6 +205,12 @@ def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return 0
     params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    # which parameters did ANY rank's loss reach?  (one tiny message; the others keep .grad = None, as under autograd)
+    has = torch.tensor([float(p.grad is not None) for p in params], dtype=torch.float32, device=params[0].device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+    params = [p for p, h in zip(params, has.tolist()) if h > 0]
     n_buckets, i = 0, 0
     while i < len(params):
         j, size = i, 0

@@ -104,3 +104,44 @@ def test_sharded_ood_scores_two_ranks_gloo():
         assert torch.allclose(torch.tensor(scores), torch.tensor(ref), rtol=1e-9, atol=0)
         assert 0 < sum(flags) < len(flags)
     assert res[0][1] == res[1][1]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cwfa_amd.training import allreduce_gradients
+        g = torch.Generator().manual_seed(7)
+        shapes = [(64, 64, 3, 3), (64,), (24, 64, 3, 3), (5,), (64, 58, 1, 1)]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+        unused = torch.nn.Parameter(torch.zeros(4))                        # no rank's loss reaches it: .grad stays None
+        full = [torch.randn(world, *s, generator=g) for s in shapes]          # every rank draws the same numbers
+        for p, f in zip(params, full):
+            p.grad = f[rank].clone()
+        if rank == 1:
+            params[3].grad = None                                            # a parameter this rank's shard never reached
+        nb = allreduce_gradients(params[:2] + [unused] + params[2:] + [frozen], bucket_bytes=64 * 64 * 9 * 4 + 1024)
+        want = [f.sum(0) if i != 3 else f[0] for i, f in enumerate(full)]
+        ok = all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-6) for p, w in zip(params, want))
+        q.put((rank, ok, nb, frozen.grad is None and unused.grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks_gloo():
+    """the ranks' gradients are SUMMED (the loss is normalised by the global batch) through flat
+    buckets; small bucket size here so that the five tensors need several messages."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ok, nb, frozen_untouched in res:
+        assert ok and frozen_untouched
+        assert nb == 2, nb            # [w0 b0] [w1 b1 w2]: a bucket closes where the next tensor no longer fits

@@ -175,3 +175,53 @@ def test_training_steps_reduce_the_nll():
         hist.append(float(nll))
         training.sgd_step(params, 0.05)
     assert hist[-1] < hist[0] and all(b <= a + 1e-6 for a, b in zip(hist, hist[1:])), hist
+
+
+def _train_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # one card here: gloo (RCCL needs one GPU per rank)
+    try:
+        from cwfa_amd import training
+        fx, g = _golden_step("g13_step_grad_k0_ch8")
+        x = torch.from_numpy(fx["x"]).cuda()
+        c = [torch.from_numpy(fx["c0"]).cuda(), torch.from_numpy(fx["c1"]).cuda()]
+        B = x.shape[0]
+        lo, hi = (0, 1) if rank == 0 else (1, B)                       # uneven shards: 1 + 2 samples
+        nll, _, _ = training.nll_backward(g, x[lo:hi].contiguous(), [t[lo:hi].contiguous() for t in c])
+        params = [p for p in g.parameters() if p.requires_grad]
+        nb = training.allreduce_gradients(params, bucket_bytes=1 << 12)
+        grads = {k: p.grad.cpu().numpy() for k, p in g.named_parameters() if p.grad is not None}     # plain arrays: no fd passing
+        q.put((rank, float(nll), nb, grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_two_ranks_on_the_gpu_path():
+    """Data-parallel training step through the product: two processes share this card, each runs forward + backward
+    on its (uneven) batch shard with the GLOBAL normalisation, the gradients are summed through flat buckets; both ranks
+    end with the loss and the gradients of the reference's single-process autograd (fixture g13)."""
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import load_golden
+    fx = load_golden("g13_step_grad_k0_ch8")
+    want = {k[len("grad/"):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("grad/")}
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, nll, nb, grads in res:
+        assert abs(nll - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+        assert nb >= 2
+        assert set(grads) == set(want)
+        for k in want:
+            assert_close(grads[k], want[k], TOL, f"rank {rank} {k}")
