@@ -142,16 +142,24 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
         if (more) issue(next);
         const float* xs = smem + buf * C::BUFW + kh * WG_CHP + cit * 32 + l31;
         const float* ds = smem + buf * C::BUFW + C::XW + kh * WG_CHP + mt * 32 + l31;
-        static_for<32>([&](auto sc) {
+        // operand registers one k-step ahead of the MFMAs that consume them (two sets), so that the LDS latency runs under
+        // the nine MFMAs of the step before (one wave per SIMD: nobody else would hide it)
+        float av[2], bv[2][C::TAPS];
+        auto fetch = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int row = s / 16, col = (2 * s) % 32;
-            const float a = ds[(2 * s) * WG_CHP];
+            av[s & 1] = ds[(2 * s) * WG_CHP];
 #pragma unroll
-            for (int i = 0; i < C::TAPS; ++i) {
-                const int ky = i / KS, kx = i % KS;
-                const float bv = xs[((row + ky) * C::XC + col + kx) * WG_CHP];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
-            }
+            for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = xs[((row + i / KS) * C::XC + col + i % KS) * WG_CHP];
+        };
+        fetch(std::integral_constant<int, 0>{});
+        static_for<32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s + 1 < 32) fetch(std::integral_constant<int, s + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < C::TAPS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         });
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -173,13 +181,33 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
     }
 }
 
+// Sum of the workers' partial filter banks in a fixed order (deterministic).  A block owns 64 consecutive filter taps; its
+// four waves each take a contiguous quarter of the workers with four independent running sums (loads in flight), and
+// the 16 sums per tap are combined in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t n,
                                                            int workers, float beta) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int w = 0; w < workers; ++w) s += part[(int64_t)w * n + i];
-    dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + li;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        const int per = (workers + 3) / 4, w0 = grp * per, w1 = min(workers, w0 + per);
+        const float* src = part + i;
+        int w = w0;
+        for (; w + 4 <= w1; w += 4) {
+            a0 += src[(int64_t)w * n];
+            a1 += src[(int64_t)(w + 1) * n];
+            a2 += src[(int64_t)(w + 2) * n];
+            a3 += src[(int64_t)(w + 3) * n];
+        }
+        for (; w < w1; ++w) a0 += src[(int64_t)w * n];
+    }
+    red[grp][li] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float s = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+    }
 }
 
 // ELU backward from the layer's OUTPUT a = ELU(q):  dq = g * (a > 0 ? 1 : a + 1)   (exp(q) = a + 1 for q <= 0), + add
@@ -203,10 +231,12 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(y + b * y_bs + i) = o;
 }
 
-int wgrad_workers(int B, int H, int W, int Cout, int Cin) {
+int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
     const int64_t strips = (int64_t)B * ((H + 1) / 2) * ((W + 31) / 32);
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int64_t w = (256 + tiles - 1) / tiles;          // one block per CU in total
+    // 3x3: one block per CU in total (104 KB of LDS each); 1x1: 65 KB each and little arithmetic per byte, so two
+    // resident blocks per CU to keep more loads in flight
+    int64_t w = ((ks == 1 ? 512 : 256) + tiles - 1) / tiles;
     if (w > strips) w = strips;
     return (int)(w < 1 ? 1 : w);
 }
@@ -215,7 +245,7 @@ int wgrad_workers(int B, int H, int W, int Cout, int Cin) {
 
 extern "C" int64_t cwfa_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int ks) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ks != 1 && ks != 3)) return 0;
-    return (int64_t)wgrad_workers(B, H, W, Cout, Cin) * Cout * Cin * ks * ks * 4;
+    return (int64_t)wgrad_workers(B, H, W, Cout, Cin, ks) * Cout * Cin * ks * ks * 4;
 }
 
 extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, int B, int Cin, int H, int W,
@@ -227,7 +257,7 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     const int64_t n = (int64_t)Cout * Cin * ks * ks;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || H == 0 || W == 0) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st,
                            reinterpret_cast<const float*>(workspace), dw, n, 0, beta);
         CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
         return CWFA_OK;
@@ -240,7 +270,7 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     const int64_t strips = (int64_t)B * p.sy * p.sx;
     CWFA_REQUIRE(strips < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: too many strips");
     p.nstrips = (int)strips;
-    const int workers = wgrad_workers(B, H, W, Cout, Cin);
+    const int workers = wgrad_workers(B, H, W, Cout, Cin, ks);
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
     if (ks == 3) {
@@ -261,7 +291,7 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), WgCfg<1>::LDS_BYTES, st, p);
     }
     CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.part, dw, n, workers, beta);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw, n, workers, beta);
     CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
     return CWFA_OK;
 }

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Time the training step (forward + backward + gradient exchange stub) of the finest CAT flow step at BASELINE.json
+configs[3]'s per-rank shape (512x512x96 volumes) and the weight-gradient kernel on its own (GPU box):
+    python tools/train_time.py [batch]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cwfa_amd import CWFA, ops, training  # noqa: E402
+
+
+def ev_time(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    torch.manual_seed(0)
+    for (cin, cout, ks) in [(64, 64, 3), (64, 64, 1), (64, 96, 3), (96, 64, 1)]:
+        x = torch.randn(B, cin, 512, 512, device="cuda")
+        dy = torch.randn(B, cout, 512, 512, device="cuda")
+        ms = ev_time(lambda: ops.conv2d_wgrad(x, dy, ks))
+        fl = 2.0 * B * cin * cout * ks * ks * 512 * 512
+        print(f"wgrad {cin}->{cout} k{ks} @512 B{B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s", flush=True)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, with_lrnn=False, device="cuda")
+    g = conv_inn[0].train()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 96, 512, 512, generator=gen).cuda()
+    c = [torch.randn(B, 48, 512, 512, generator=gen).cuda(), 0.1 * torch.randn(B, 48, 512, 512, generator=gen).cuda()]
+    params = [p for p in g.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        training.nll_backward(g, x, c)
+
+    with torch.no_grad():
+        fwd = ev_time(lambda: CWFA.nll_step(g, x, c), reps=5)
+    ms = ev_time(step, reps=5)
+    n_par = sum(p.numel() for p in params if p.grad is not None)
+    print(f"flow step 0 (48 flow channels, 5 CAT blocks) @512x512x96 B{B}: inference forward {fwd:.2f} ms, training step "
+          f"(forward with tape + backward) {ms:.2f} ms = {B/ms*1e3:.2f} volumes/s; {n_par/1e6:.2f} M parameters with gradients; "
+          f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()
