@@ -70,7 +70,7 @@ SIGNATURES = {
     "cwfa_bn_running_update_f32": (i, [p, C.c_double, f, p, p, p, i, p]),
     "cwfa_chain_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), p, p, i, i, i, i, i64, i64, i64, f, f, p]),
     "cwfa_conv2d_wgrad_workspace_bytes": (i64, [i, i, i, i, i, i]),
-    "cwfa_conv2d_wgrad_f32": (i, [p, p, p, p, i, i, i, i, i, i, i64, i64, f, p]),
+    "cwfa_conv2d_wgrad_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, i64, i64, f, p]),
     "cwfa_elu_bwd_f32": (i, [p, p, p, p, i, i64, i64, i64, i64, i64, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),

@@ -31,6 +31,7 @@ struct WgParams {
     const float* x;
     const float* dy;
     float* part;
+    float* bpart;      // nullable: per-worker partial bias gradients [worker][Cout]
     int B, Cin, H, W, Cout;
     int64_t x_bs, dy_bs;
     int sx, sy;        // strips per row / per column of strips
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
     // staging roles (see header): core columns -- col = tid & 31, pair = (tid >> 5) + 8 j
     const int scol = tid & 31, sq = tid >> 5;
     float xr[C::XLOADS], hr[C::HLOADS ? C::HLOADS : 1], dr[16];
+    float bacc = 0.f;        // running sum of this lane's A operands = sum over pixels of dy[co]: the bias gradient
 
     auto issue = [&](int strip) {
         const int b = strip / (p.sy * p.sx), rem = strip - b * (p.sy * p.sx);
@@ -159,11 +161,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < C::TAPS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][i], acc[i], 0, 0, 0);
+            bacc += av[s & 1];
             __builtin_amdgcn_sched_barrier(0);
         });
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+
+    // bias gradient: lane (l31, kh) of an m-tile's wave has summed dy[co0 + mt*32 + l31] over the pixels of parity kh
+    {
+        const float tot = bacc + __shfl_xor(bacc, 32, 64);
+        const int co = co0 + mt * 32 + l31;
+        if (p.bpart && blockIdx.z == 0 && cit == 0 && kh == 0 && co < p.Cout) p.bpart[(int64_t)blockIdx.x * p.Cout + co] = tot;
     }
 
     // partial filter bank of this pixel worker: part[worker][co][ci][tap]
@@ -245,11 +255,11 @@ int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
 
 extern "C" int64_t cwfa_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int ks) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ks != 1 && ks != 3)) return 0;
-    return (int64_t)wgrad_workers(B, H, W, Cout, Cin, ks) * Cout * Cin * ks * ks * 4;
+    return (int64_t)wgrad_workers(B, H, W, Cout, Cin, ks) * ((int64_t)Cout * Cin * ks * ks + Cout) * 4;
 }
 
-extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, int B, int Cin, int H, int W,
-                                     int Cout, int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream) {
+extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* db, void* workspace, int B, int Cin, int H,
+                                     int W, int Cout, int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream) {
     CWFA_REQUIRE(x && dy && dw && workspace, CWFA_E_INVAL, "cwfa_conv2d_wgrad_f32: null pointer");
     CWFA_REQUIRE(ks == 1 || ks == 3, CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: kernel size %d (1 and 3 are built)", ks);
     CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: bad shape");
@@ -260,6 +270,11 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st,
                            reinterpret_cast<const float*>(workspace), dw, n, 0, beta);
         CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+        if (db) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(workspace), db, (int64_t)Cout, 0, beta);
+            CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+        }
         return CWFA_OK;
     }
     WgParams p{};
@@ -271,6 +286,7 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     CWFA_REQUIRE(strips < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: too many strips");
     p.nstrips = (int)strips;
     const int workers = wgrad_workers(B, H, W, Cout, Cin, ks);
+    p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
     if (ks == 3) {
@@ -293,6 +309,11 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw, n, workers, beta);
     CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+    if (db) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p.bpart, db, (int64_t)Cout, workers,
+                           beta);
+        CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+    }
     return CWFA_OK;
 }
 

@@ -413,9 +413,10 @@ def subnet_layer(x, pc3, b3, panel1, b1):
 _wgrad_ws = {}
 
 
-def conv2d_wgrad(x, dy, ks, out=None, accumulate=False):
+def conv2d_wgrad(x, dy, ks, out=None, accumulate=False, bias_out=None, want_bias=False):
     """dW [Cout,Cin,ks,ks] of a stride-1 'same' convolution y = conv(x, W): sum over batch and pixels of dy (x) shifted x.
-    With ``out`` and ``accumulate`` the result is added to ``out`` (a .grad buffer)."""
+    With ``out`` and ``accumulate`` the result is added to ``out`` (a .grad buffer).  ``want_bias`` / ``bias_out``: also the
+    bias gradient sum(dy) [Cout] from the same pass (returned as second value; accumulated like ``out``)."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     dy, dbs = planes(dy, "dy")
@@ -428,14 +429,20 @@ def conv2d_wgrad(x, dy, ks, out=None, accumulate=False):
         accumulate = False
     elif tuple(out.shape) != (Cout, Cin, ks, ks) or not out.is_contiguous():
         raise ValueError("conv2d_wgrad: `out` must be a contiguous [Cout,Cin,ks,ks] tensor")
+    if bias_out is None and want_bias:
+        if accumulate:
+            raise ValueError("conv2d_wgrad: accumulate needs an existing bias_out")
+        bias_out = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    if bias_out is not None and (tuple(bias_out.shape) != (Cout,) or not bias_out.is_contiguous()):
+        raise ValueError("conv2d_wgrad: `bias_out` must be a contiguous [Cout] tensor")
     nbytes = L.cwfa_conv2d_wgrad_workspace_bytes(B, Cin, H, W, Cout, ks)
     key = (x.device, torch.cuda.current_stream().cuda_stream)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _wgrad_ws[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-    check(L.cwfa_conv2d_wgrad_f32(_p(x), _p(dy), _p(out), _p(ws), B, Cin, H, W, Cout, ks, xbs, dbs, 1.0 if accumulate else 0.0,
-                                  _stream()), "conv2d_wgrad")
-    return out
+    check(L.cwfa_conv2d_wgrad_f32(_p(x), _p(dy), _p(out), _p(bias_out), _p(ws), B, Cin, H, W, Cout, ks, xbs, dbs,
+                                  1.0 if accumulate else 0.0, _stream()), "conv2d_wgrad")
+    return (out, bias_out) if bias_out is not None else out
 
 
 def elu_bwd(g, a, add=None, out=None):

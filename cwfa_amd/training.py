@@ -71,23 +71,21 @@ def _packT(conv):
     return hit[0]
 
 
-def _acc_grad(param, g):
-    if param.grad is None:
-        param.grad = g
-    else:
-        param.grad.add_(g)
-
-
 def _conv_param_grads(conv, x, dy):
     """Accumulate dL/dW, dL/db of ``y = conv(x)`` into conv.weight.grad / conv.bias.grad."""
     ks = conv.kernel_size[0]
-    w = conv.weight
+    w, b = conv.weight, conv.bias
+    if b is not None and (w.grad is None) != (b.grad is None):            # mixed state: give the missing one zeros
+        for t in (w, b):
+            if t.grad is None:
+                t.grad = torch.zeros_like(t)
     if w.grad is None:
-        w.grad = ops.conv2d_wgrad(x, dy, ks)
+        if b is None:
+            w.grad = ops.conv2d_wgrad(x, dy, ks)
+        else:
+            w.grad, b.grad = ops.conv2d_wgrad(x, dy, ks, want_bias=True)      # sum(dy) comes out of the same pass
     else:
-        ops.conv2d_wgrad(x, dy, ks, out=w.grad, accumulate=True)
-    if conv.bias is not None:
-        _acc_grad(conv.bias, ops.channel_stats(dy).view(-1, 2)[:, 0].to(torch.float32))
+        ops.conv2d_wgrad(x, dy, ks, out=w.grad, accumulate=True, bias_out=None if b is None else b.grad)
 
 
 def subnet_backward(tape, g_a, want_input_grad=False):

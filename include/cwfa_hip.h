@@ -295,11 +295,12 @@ int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, co
 
 /* Weight gradient of a stride-1, zero-padded ("same") convolution, ks = 1 or 3, on the fp32 matrix cores:
  *   dw[co][ci][ky][kx] = beta * dw + sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-ks/2][x+kx-ks/2]     (torch layout)
+ * and, with db != NULL, the bias gradient db[co] = beta * db + sum_{b,y,x} dy[b][co][y][x] from the same pass over dy.
  * x [B,Cin,H,W] (batch stride x_bs), dy [B,Cout,H,W] (dy_bs).  workspace: cwfa_conv2d_wgrad_workspace_bytes() bytes
  * (per-worker partial filter banks, summed in a fixed order: the result is deterministic). */
 int64_t cwfa_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int ks);
-int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout,
-                          int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream);
+int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* db, void* workspace, int B, int Cin, int H, int W,
+                          int Cout, int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream);
 
 /* ELU backward from the layer output a = ELU(q):  y = g * (a > 0 ? 1 : a + 1) (+ add, nullable).  n elements per sample
  * (multiple of 4), batch strides in elements. */

@@ -33,14 +33,17 @@ def test_conv_weight_gradient_vs_autograd(cfg):
     dy = torch.randn(B, Cout, H, W, generator=g)
     w = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
     (F.conv2d(x.double(), w, padding=ks // 2) * dy.double()).sum().backward()
-    got = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks)
+    got, gb = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks, want_bias=True)
     assert_close(got, w.grad, TOL, f"dW {cfg}")
+    assert_close(gb, dy.double().sum((0, 2, 3)), TOL, f"db {cfg}")
     # accumulate into an existing gradient buffer; channel-sliced (strided-batch) operands
     base = torch.randn(Cout, Cin, ks, ks, generator=g)
     xb = torch.randn(B, Cin + 3, H, W, generator=g)
     xb[:, 2:2 + Cin] = x
-    acc = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), ks, out=base.cuda().clone(), accumulate=True)
+    bb = torch.randn(Cout, generator=g)
+    acc, accb = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), ks, out=base.cuda().clone(), accumulate=True, bias_out=bb.cuda().clone())
     assert_close(acc, w.grad + base.double(), TOL, f"dW accumulate {cfg}")
+    assert_close(accb, dy.double().sum((0, 2, 3)) + bb.double(), TOL, f"db accumulate {cfg}")
     # deterministic: the partial sums are combined in a fixed order
     assert torch.equal(got, ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks))
 
