@@ -233,6 +233,11 @@ def main():
                 res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3), B)
             except Exception as exc:                          # noqa: BLE001
                 res["experiment_split_bf16"] = {"error": repr(exc)[:300]}
+        if world == 1 and not a.no_lrnn and not a.no_experiment:
+            try:
+                res["experiment_train_step"] = train_experiment(conv_inn, dev, a, max(a.steps // 4, 3))
+            except Exception as exc:                          # noqa: BLE001
+                res["experiment_train_step"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
             try:
                 res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
@@ -263,6 +268,44 @@ def split_experiment(ops, step, steps, batch):
             "note": "opt-in, not the headline configuration: operands split exactly into three bf16 pieces, six partial "
                     "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; parity tests hold the fp32 path's bounds "
                     "(tests/test_gpu_parity.py::test_split_bf16_*)"}
+
+
+def train_experiment(conv_inn, dev, a, steps):
+    """NOT the headline: SURVEY.md 8(f) row 1 -- one training step (forward with tape + backward, CWFA.py:966-1006) of
+    the finest flow step (D_0 -> 48 flow channels, 5 CAT blocks) on one synthetic volume, conditions as inputs, measured
+    after the timed region."""
+    from cwfa_amd import training
+    g = conv_inn[0]
+    was_training = g.training
+    g.train()
+    B, D, S = 1, a.depths, a.side
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, D, S, S, generator=gen).to(dev)
+    c = [torch.randn(B, D // 2, S, S, generator=gen).to(dev), (0.1 * torch.randn(B, D // 2, S, S, generator=gen)).to(dev)]
+    params = [p for p in g.parameters() if p.requires_grad]
+
+    def one():
+        for p in params:
+            p.grad = None
+        return training.nll_backward(g, x, c)[0]
+
+    try:
+        one(); one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nll = one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        n_par = sum(p.numel() for p in params if p.grad is not None)
+    finally:
+        for p in params:
+            p.grad = None
+        g.train(was_training)
+    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "nll": float(nll),
+            "parameters_with_gradients": n_par,
+            "note": "flow step 0 only, conditions given; gradients of the step's own parameters pinned to the reference's "
+                    "autograd by tests/test_gpu_backward.py (fixture g13)"}
 
 
 def pmc_traffic(dom, a):
