@@ -271,7 +271,7 @@ def split_experiment(ops, step, steps, batch):
 
 
 def train_experiment(conv_inn, dev, a, steps):
-    """NOT the headline: SURVEY.md 8(f) row 1 -- one training step (forward with tape + backward, CWFA.py:966-1006) of
+    """NOT the headline: SURVEY.md 8(f) row 1 -- one training step (inverse + forward with tape + backward, CWFA.py:905-1006) of
     the finest flow step (D_0 -> 48 flow channels, 5 CAT blocks) on one synthetic volume, conditions as inputs, measured
     after the timed region."""
     from cwfa_amd import training
@@ -284,10 +284,12 @@ def train_experiment(conv_inn, dev, a, steps):
     c = [torch.randn(B, D // 2, S, S, generator=gen).to(dev), (0.1 * torch.randn(B, D // 2, S, S, generator=gen)).to(dev)]
     params = [p for p in g.parameters() if p.requires_grad]
 
-    def one():
+    low = torch.randn(B, D // 2, S, S, generator=gen).to(dev)
+
+    def one():                                   # the default loss: 0.40984 * mse(gt, xhat(z = 0)) + 0.59016 * NLL (main.py:43,107)
         for p in params:
             p.grad = None
-        return training.nll_backward(g, x, c)[0]
+        return training.step_backward(g, x, c, low=low)["full_loss"]
 
     try:
         one(); one()
@@ -302,7 +304,7 @@ def train_experiment(conv_inn, dev, a, steps):
         for p in params:
             p.grad = None
         g.train(was_training)
-    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "nll": float(nll),
+    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "full_loss": float(nll),
             "parameters_with_gradients": n_par,
             "note": "flow step 0 only, conditions given; gradients of the step's own parameters pinned to the reference's "
                     "autograd by tests/test_gpu_backward.py (fixture g13)"}

@@ -641,10 +641,27 @@ __device__ __forceinline__ float soft_clamp_grad(float a, int kind, float clamp)
     }
 }
 
+// dL/ds, dL/dt of a stage -> gradients of the tensors the sub-network produced (through the soft clamp / the scalings)
+__device__ __forceinline__ void store_stage_grads(const cwfa_affine_stage& st, const cwfa_chain_grads& gr, int k, int b, int64_t off,
+                                                  float ds, float dt, int accumulate) {
+    if (gr.ds[k]) {
+        const float a = st.s_raw[b * st.s_bs + off] * st.pre_scale;
+        const float v = ds * soft_clamp_grad(a, st.clamp_kind, st.clamp) * st.pre_scale;
+        float* dst = gr.ds[k] + b * gr.ds_bs[k] + off;
+        *dst = accumulate ? *dst + v : v;
+    }
+    if (gr.dt[k]) {
+        const float v = st.t_neg_div_sqrt2 ? (-dt) / CWFA_SQRT2_F : dt * st.pre_scale;
+        float* dst = gr.dt[k] + b * gr.dt_bs[k] + off;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
 __global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gz, cwfa_chain ch,
                                                         cwfa_chain_grads gr, const int64_t* __restrict__ final_perm,
                                                         float* __restrict__ gv0, int C, int H, int W, int64_t z_bs,
-                                                        int64_t gz_bs, int64_t gv0_bs, float gscale, float ldscale) {
+                                                        int64_t gz_bs, int64_t gv0_bs, float gscale, float ldscale,
+                                                        int accumulate) {
     const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -661,11 +678,7 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict_
             float s, t;
             stage_st(st, b, off, s, t);
             const float e = v - t;
-            if (gr.ds[k]) {
-                const float a = st.s_raw[b * st.s_bs + off] * st.pre_scale;
-                gr.ds[k][b * gr.ds_bs[k] + off] = (g * e - ldscale) * soft_clamp_grad(a, st.clamp_kind, st.clamp) * st.pre_scale;
-            }
-            if (gr.dt[k]) gr.dt[k][b * gr.dt_bs[k] + off] = st.t_neg_div_sqrt2 ? (-g) / CWFA_SQRT2_F : g * st.pre_scale;
+            store_stage_grads(st, gr, k, b, off, g * e - ldscale, g, accumulate);
             v = e * expf(-s);
             g = g * expf(s);
             p = gather_pos(p, st.perm, st.perm_axis);
@@ -674,9 +687,67 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict_
     if (gv0) gv0[b * gv0_bs + lin(p, H, W)] = g;
 }
 
+// Backward of a reconstruction loss on the INVERSE pass (CWFA.py:952-959: F.l1_loss / F.mse_loss(curr_gt, upsampled_vol),
+// upsampled_vol = graph([z, low], c, rev=True) CWFA.py:911) through the inverse chain, again without stored activations.
+// xhat = Haar1D^-1(cat[low, v0]) and the inverse stages are v_k = G_k^-1((v_{k+1} - t_k) e^{-s_k}); with w_k = G_k(v_k):
+//     dL/dt_k = -g e^{-s},   dL/ds_k = -g w_k,   g <- g e^{-s},   w_k -> v_{k+1} = e^{s} w_k + t
+// where g starts as the detail band of Haar1D(dL/dxhat) (the transform is orthonormal) and both v and g travel along the
+// forward chain's pull walk -- the thread owning a position of v_n walks the gathers back to v_0, loads
+// v_0 = hi(xhat), g_0 = gscale * hi(loss'(xhat - gt)) there and applies the stages forwards.  `ch` is the FORWARD-order
+// chain.  loss_sum (nullable) += sum |xhat - gt|^p over the elements (p = loss_kind: 1 or 2).
+__global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ gt,
+                                                            cwfa_chain ch, cwfa_chain_grads gr, int C, int H, int W,
+                                                            int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind,
+                                                            int accumulate, double* __restrict__ loss_sum) {
+    __shared__ double red[16];
+    const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    double lsum = 0.0;
+    if (i < n) {
+        Pos p{(int)(i / HW), (int)((i / W) % H), (int)(i % W)};
+        int64_t off[CWFA_CHAIN_MAX];
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k) {
+            if (k < ch.n_stages) {
+                off[k] = lin(p, H, W);
+                p = gather_pos(p, ch.stage[k].perm, ch.stage[k].perm_axis);
+            }
+        }
+        const int64_t pix = (int64_t)p.h * W + p.w;
+        const float x0 = xhat[b * xhat_bs + (int64_t)(2 * p.c) * HW + pix], x1 = xhat[b * xhat_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+        const float d0 = x0 - gt[b * gt_bs + (int64_t)(2 * p.c) * HW + pix], d1 = x1 - gt[b * gt_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+        float v = (x0 - x1) * CWFA_INV_SQRT2_F, g;
+        if (loss_kind == 2) {
+            g = gscale * ((d0 - d1) * CWFA_INV_SQRT2_F);
+            lsum = (double)d0 * d0 + (double)d1 * d1;
+        } else {
+            const float s0 = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f), s1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+            g = gscale * ((s0 - s1) * CWFA_INV_SQRT2_F);
+            lsum = (double)fabsf(d0) + (double)fabsf(d1);
+        }
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k) {
+            if (k < ch.n_stages) {
+                const cwfa_affine_stage& st = ch.stage[k];
+                float s, t;
+                stage_st(st, b, off[k], s, t);
+                const float ge = g * expf(-s);
+                store_stage_grads(st, gr, k, b, off[k], -g * v, -ge, accumulate);
+                g = ge;
+                v = expf(s) * v + t;
+            }
+        }
+    }
+    if (loss_sum) {
+        const double tot = cwfa_block_sum(lsum, red);
+        if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+    }
+}
+
 extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                                   const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                                  int64_t gv0_bs, float gscale, float ldscale, void* stream);
+                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream);
 
 static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds) {
     *lds = (size_t)(2 * ch->n_stages + 1) * W * sizeof(float);
@@ -814,7 +885,7 @@ extern "C" int cwfa_extract_views_f32(const float* image, const int* coords_yx, 
 static int check_chain(const char* name, const cwfa_chain* ch);
 extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                                   const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                                  int64_t gv0_bs, float gscale, float ldscale, void* stream) {
+                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream) {
     CWFA_REQUIRE(z && grads, CWFA_E_INVAL, "cwfa_chain_bwd_f32: null pointer");
     CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_bwd_f32: bad shape");
     int rc = check_chain("cwfa_chain_bwd_f32", ch);
@@ -825,7 +896,26 @@ extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_ch
     if (B == 0 || n == 0) return CWFA_OK;
     dim3 grid((unsigned)((n + 255) / 256), B);
     hipLaunchKernelGGL(chain_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, gz, *ch, *grads, final_perm, gv0, C, H, W, z_bs,
-                       gz_bs, gv0_bs, gscale, ldscale);
+                       gz_bs, gv0_bs, gscale, ldscale, accumulate);
     CWFA_LAUNCH_CHECK("cwfa_chain_bwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_chain_inv_bwd_f32(const float* xhat, const float* gt, const cwfa_chain* ch, const cwfa_chain_grads* grads, int B,
+                                      int C, int H, int W, int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind, int accumulate,
+                                      double* loss_sum, void* stream) {
+    CWFA_REQUIRE(xhat && gt && grads, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_inv_bwd_f32: bad shape");
+    CWFA_REQUIRE(loss_kind == 1 || loss_kind == 2, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: loss_kind %d (1 = L1, 2 = L2)", loss_kind);
+    int rc = check_chain("cwfa_chain_inv_bwd_f32", ch);
+    if (rc) return rc;
+    for (int k = 0; k < ch->n_stages; ++k)
+        CWFA_REQUIRE(!grads->ds[k] || ch->stage[k].s_raw, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: stage %d has no s but a ds buffer", k);
+    const int64_t n = (int64_t)C * H * W;
+    if (B == 0 || n == 0) return CWFA_OK;
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(chain_inv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, xhat, gt, *ch, *grads, C, H, W, xhat_bs, gt_bs,
+                       gscale, loss_kind, accumulate, loss_sum);
+    CWFA_LAUNCH_CHECK("cwfa_chain_inv_bwd_f32");
     return CWFA_OK;
 }

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "chain_inv_bwd", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -215,14 +215,8 @@ def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
     return z, low
 
 
-def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=None, want_input_grad=False):
-    """Backward of L = gscale*0.5*sum z^2 - ldscale*sum logdet (+ <gz, z>) through the chain that produced ``z``
-    (``chain_fwd`` with the same ``stages`` / ``final_perm``).  ``grads[k] = (ds_raw_k, dt_k)``: preallocated
-    [B,C,H,W] views (contiguous planes) or None.  Returns dL/d(detail band) if ``want_input_grad``."""
-    L = _lib.lib()
-    z, zbs = planes(z, "z")
-    B, Cc, H, W = z.shape
-    ch, keep = _chain(stages)
+def _chain_grads(grads, shape):
+    B, Cc, H, W = shape
     gr = _lib.ChainGrads()
     for k, (ds, dt) in enumerate(grads):
         for name, t in (("ds", ds), ("dt", dt)):
@@ -230,15 +224,45 @@ def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=Non
                 continue
             t2, bs = planes(t, name)
             if t2.data_ptr() != t.data_ptr() or tuple(t.shape) != (B, Cc, H, W):
-                raise ValueError(f"chain_bwd: {name}[{k}] must be a [B,C,H,W] view with contiguous planes")
+                raise ValueError(f"chain backward: {name}[{k}] must be a [B,C,H,W] view with contiguous planes")
             getattr(gr, name)[k] = t.data_ptr()
             getattr(gr, name + "_bs")[k] = bs
+    return gr
+
+
+def chain_inv_bwd(xhat, gt, stages, grads, gscale, loss_kind=2, accumulate=False):
+    """Backward of gscale-weighted sum |xhat - gt|^p (p = loss_kind) through the inverse pass that produced ``xhat``;
+    ``stages`` in FORWARD order.  Returns the float64[1] tensor sum |xhat - gt|^p."""
+    L = _lib.lib()
+    xhat, xbs = planes(xhat, "xhat")
+    gt, gbs = planes(gt, "gt")
+    if tuple(xhat.shape) != tuple(gt.shape):
+        raise ValueError("chain_inv_bwd: xhat and gt differ in shape")
+    B, D, H, W = xhat.shape
+    Cc = D // 2
+    ch, keep = _chain(stages)
+    gr = _chain_grads(grads, (B, Cc, H, W))
+    loss = torch.zeros(1, dtype=torch.float64, device=xhat.device)
+    check(L.cwfa_chain_inv_bwd_f32(_p(xhat), _p(gt), C.byref(ch), C.byref(gr), B, Cc, H, W, xbs, gbs, float(gscale), int(loss_kind),
+                                   int(bool(accumulate)), _p(loss), _stream()), "chain_inv_bwd")
+    return loss
+
+
+def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=None, want_input_grad=False, accumulate=False):
+    """Backward of L = gscale*0.5*sum z^2 - ldscale*sum logdet (+ <gz, z>) through the chain that produced ``z``
+    (``chain_fwd`` with the same ``stages`` / ``final_perm``).  ``grads[k] = (ds_raw_k, dt_k)``: preallocated
+    [B,C,H,W] views (contiguous planes) or None.  Returns dL/d(detail band) if ``want_input_grad``."""
+    L = _lib.lib()
+    z, zbs = planes(z, "z")
+    B, Cc, H, W = z.shape
+    ch, keep = _chain(stages)
+    gr = _chain_grads(grads, (B, Cc, H, W))
     gzbs = 0
     if gz is not None:
         gz, gzbs = planes(gz, "gz")
     gv0 = torch.empty((B, Cc, H, W), dtype=torch.float32, device=z.device) if want_input_grad else None
     check(L.cwfa_chain_bwd_f32(_p(z), _p(gz), C.byref(ch), C.byref(gr), _p(_idx(final_perm)), _p(gv0), B, Cc, H, W, zbs, gzbs,
-                               Cc * H * W, float(gscale), float(ldscale), _stream()), "chain_bwd")
+                               Cc * H * W, float(gscale), float(ldscale), int(bool(accumulate)), _stream()), "chain_bwd")
     return gv0
 
 

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 
-__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "allreduce_gradients", "sgd_step"]
+__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "allreduce_gradients", "sgd_step"]
 
 
 class _Tape:
@@ -108,34 +108,61 @@ def subnet_backward(tape, g_a, want_input_grad=False):
 
 
 def nll_backward(graph, x, c, group=None, want_cond_grads=False):
-    """One training-step forward + backward of a CAT flow step on this rank's batch shard.
+    """One training-step forward + backward of a CAT flow step's NLL on this rank's batch shard.
 
     Returns ``(nll, Z, cond_grads)``: the global-batch NLL of CWFA.py:978 (identical on every rank), the forward
     outputs, and dL/d(condition) per condition tensor (or None).  Parameter gradients are accumulated into ``.grad``
     (LOCAL contributions: call ``allreduce_gradients`` before the optimiser step when running on several ranks)."""
+    out = step_backward(graph, x, c, group=group, want_cond_grads=want_cond_grads, cond_weight=0.0)
+    return out["nll"], out["Z"], out["cond_grads"]
+
+
+def step_backward(graph, gt, c, low=None, z=None, cond_weight=0.40984, loss_func="L2", group=None, want_cond_grads=False):
+    """Forward + backward of the reference's training loss of one CAT flow step (CWFA.py:905-911,952-987):
+
+        full_loss = cond_weight * loss_func(gt, xhat) + (1 - cond_weight) * NLL,
+        xhat = graph([z, low], c, rev=True)  (the reconstruction, z sampled by the caller or None = 0),
+        NLL  = (0.5*||Z0||^2 - mean_b logdet) / numel,  Z = graph(gt, c).
+
+    The reference evaluates every sub-network twice (inverse and forward pass) and lets autograd add the two gradient
+    contributions; both passes see the same conditions, so here the sub-networks run ONCE (with a tape), the two chain
+    backward kernels add their coefficient gradients in place, and one sub-network backward follows.
+    ``cond_weight = 0`` or ``low is None``: the NLL alone.  ``loss_func``: "L1" | "L2" (main.py:43).
+    Returns a dict: full_loss, nll, recon (mean), Z, xhat, cond_grads."""
     from .CWFA import allreduce_nll
     plan = getattr(graph, "_plan", None)
     if plan is None:
-        raise NotImplementedError("nll_backward: only conditional-affine (CAT) steps lowered to a chain plan are built")
+        raise NotImplementedError("step_backward: only conditional-affine (CAT) steps lowered to a chain plan are built")
+    if loss_func not in ("L1", "L2"):
+        raise NotImplementedError(f"step_backward: loss_func {loss_func!r} (L1 and L2 are built)")
+    recon = low is not None and cond_weight != 0.0
+    w_c = float(cond_weight) if recon else 0.0
+    x = gt
     cond_of = dict(zip(graph.condition_nodes, c))
-    tapes = []
+    tapes, cache = [], {}
 
     def coefficients(module, parts):
+        hit = cache.get(id(module))
+        if hit is not None:                              # second direction: same conditions, same coefficients
+            return hit
         net, n_s = module.subnet, module.channels
         if not hasattr(net, "block12"):
-            raise NotImplementedError("nll_backward: sub-network type without a HIP backward")
+            raise NotImplementedError("step_backward: sub-network type without a HIP backward")
         if net.normal:
             u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
             a, tape = subnet_forward_train(net, u, net.block12, net.block72[1])
             tapes.append((tape, a, parts, "normal"))
-            return a[:, :n_s], a[:, n_s:], False
-        n = net.c_in // 2
-        if not (len(parts) == 2 and parts[1].shape[1] == n and net.c_out // 2 == n_s):
-            raise NotImplementedError("nll_backward: `_first` sub-network with an unexpected condition layout")
-        mean, om = parts
-        a, tape = subnet_forward_train(net, om, net.block1, net.block7[1])
-        tapes.append((tape, a, parts, "first"))
-        return a, mean, True
+            res = (a[:, :n_s], a[:, n_s:], False)
+        else:
+            n = net.c_in // 2
+            if not (len(parts) == 2 and parts[1].shape[1] == n and net.c_out // 2 == n_s):
+                raise NotImplementedError("step_backward: `_first` sub-network with an unexpected condition layout")
+            mean, om = parts
+            a, tape = subnet_forward_train(net, om, net.block1, net.block7[1])
+            tapes.append((tape, a, parts, "first"))
+            res = (a, mean, True)
+        cache[id(module)] = res
+        return res
 
     stages, pending = plan._stages(cond_of, False, coefficients=coefficients)
     final_perm = None
@@ -144,18 +171,24 @@ def nll_backward(graph, x, c, group=None, want_cond_grads=False):
             final_perm = pending[0]
         else:
             stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
+    xhat = None
+    if recon:
+        rstages, rpending = plan._stages(cond_of, True, coefficients=coefficients)
+        if rpending is not None:
+            rstages.append(ops.stage(None, None, perm=rpending[0], axis=rpending[1]))
+        xhat = ops.chain_inv(z, low, rstages)
     B = x.shape[0]
     logdet = torch.zeros(B, dtype=torch.float64, device=x.device)
     sumsq = torch.zeros(1, dtype=torch.float64, device=x.device)
-    z, low = ops.chain_fwd(x, stages, final_perm, logdet=logdet, sumsq=sumsq)
+    zf, lowf = ops.chain_fwd(x, stages, final_perm, logdet=logdet, sumsq=sumsq)
     terms = torch.stack([sumsq[0], logdet.sum(), torch.tensor(float(B), dtype=torch.float64, device=x.device)])
     terms = allreduce_nll(terms, group)
     Bg = float(terms[2])
     numel_total = Bg * x[0].numel()             # `upsampled_vol.numel()`: the step's whole input volume (CWFA.py:911,978)
     nll = (0.5 * terms[0] - terms[1] / terms[2]) / numel_total
 
-    # backward: chain (one launch), then every block's sub-network
-    Cc, H, W = z.shape[1:]
+    # backward: the chains (one launch per direction), then every block's sub-network
+    Cc, H, W = zf.shape[1:]
     grads, holders = [], []
     it = iter(tapes)
     for st, _keep in stages:
@@ -163,16 +196,22 @@ def nll_backward(graph, x, c, group=None, want_cond_grads=False):
             grads.append((None, None))
             continue
         tape, a, parts, kind = next(it)
+        g_a = torch.empty_like(a)
         if kind == "normal":
-            g_a = torch.empty_like(a)
             grads.append((g_a[:, :Cc], g_a[:, Cc:]))
             holders.append((tape, g_a, None, parts))
         else:
-            g_a = torch.empty_like(a)
             g_mean = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device) if want_cond_grads else None
             grads.append((g_a, g_mean))
             holders.append((tape, g_a, g_mean, parts))
-    ops.chain_bwd(z, stages, grads, final_perm, gscale=1.0 / numel_total, ldscale=1.0 / (Bg * numel_total))
+    recon_mean = None
+    if recon:
+        kind = 2 if loss_func == "L2" else 1
+        rsum = ops.chain_inv_bwd(xhat, x, stages, grads, gscale=w_c * kind / numel_total, loss_kind=kind)
+        rsum = allreduce_nll(rsum, group)
+        recon_mean = rsum[0] / numel_total
+    ops.chain_bwd(zf, stages, grads, final_perm, gscale=(1.0 - w_c) / numel_total, ldscale=(1.0 - w_c) / (Bg * numel_total),
+                  accumulate=recon)
     cond_grads = None
     if want_cond_grads:
         cond_grads = {id(t): None for t in c}
@@ -192,7 +231,8 @@ def nll_backward(graph, x, c, group=None, want_cond_grads=False):
             cond_grads[id(t)] = g.contiguous() if cur is None else ops.axpby(g, 1.0, cur, 1.0)
     if want_cond_grads:
         cond_grads = [cond_grads[id(t)] for t in c]
-    return nll, (z, low), cond_grads
+    full = (1.0 - w_c) * nll + (w_c * recon_mean if recon else 0.0)
+    return {"full_loss": full, "nll": nll, "recon": recon_mean, "Z": (zf, lowf), "xhat": xhat, "cond_grads": cond_grads}
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):

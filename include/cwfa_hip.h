@@ -288,10 +288,20 @@ typedef struct {
 
 /* L = gscale * 0.5 * sum z^2 - ldscale * sum_b logdet_b (+ <gz, z> for an upstream gradient gz, nullable), z the output
  * of cwfa_chain_fwd_f32 with the same chain / final_perm.  No stored activations: every stage input is recomputed by
- * inverting the stage.  gv0 (nullable) receives dL/d(detail band entering the chain). */
+ * inverting the stage.  gv0 (nullable) receives dL/d(detail band entering the chain).  accumulate != 0: the stage
+ * gradients are ADDED to the buffers. */
 int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                        const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                       int64_t gv0_bs, float gscale, float ldscale, void* stream);
+                       int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream);
+
+/* Backward of the reconstruction term (CWFA.py:952-959: F.l1_loss / F.mse_loss(curr_gt, upsampled_vol)) through the
+ * INVERSE pass xhat = cwfa_chain_inv_f32(z, low, ...) (CWFA.py:911): L = gscale' * sum |xhat - gt|^p, p = loss_kind
+ * (1: gscale = weight/numel, 2: gscale = 2*weight/numel).  `ch` is the FORWARD-order chain (as for cwfa_chain_fwd_f32);
+ * the gradients go to the same buffers as cwfa_chain_bwd_f32's (accumulate != 0: added) since both passes use the same
+ * coefficients.  loss_sum (nullable, double[1]) += sum |xhat - gt|^p.  No stored activations. */
+int cwfa_chain_inv_bwd_f32(const float* xhat, const float* gt, const cwfa_chain* ch, const cwfa_chain_grads* grads, int B, int C,
+                           int H, int W, int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind, int accumulate,
+                           double* loss_sum, void* stream);
 
 /* Weight gradient of a stride-1, zero-padded ("same") convolution, ks = 1 or 3, on the fp32 matrix cores:
  *   dw[co][ci][ky][kx] = beta * dw + sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-ks/2][x+kx-ks/2]     (torch layout)

@@ -399,6 +399,26 @@ def gen_step_grad():
         loss = (0.5 * torch.norm(Z[0]) ** 2 - log_jac_det.mean()) / x.numel()      # upsampled_vol has x's shape (CWFA.py:911,978)
         loss.backward()
         grads = {"grad/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None}
+        if n_ch == 8:
+            # the default training loss: 0.40984 * F.mse_loss(curr_gt, upsampled_vol) + 0.59016 * NLL, upsampled_vol from the
+            # inverse pass with a sampled z (CWFA.py:905-911,952-959,978,987; main.py:43,107); L1 variant as well
+            import torch.nn.functional as F
+            w_c = 0.40984
+            z_in = 0.5 * torch.randn(B, Cn, H, W, generator=g)
+            low_in = torch.randn(B, Cn, H, W, generator=g)
+            for kind, fn in (("l2", F.mse_loss), ("l1", F.l1_loss)):
+                for p in inn.parameters():
+                    p.grad = None
+                c2 = [t.detach().clone().requires_grad_() for t in c]
+                xhat, _ = inn([z_in, low_in], c=c2, rev=True)
+                Z2, ld2 = inn(x, c=c2)
+                nll2 = (0.5 * torch.norm(Z2[0]) ** 2 - ld2.mean()) / xhat.numel()
+                full = w_c * fn(x, xhat) + (1 - w_c) * nll2
+                full.backward()
+                grads.update({f"grad_{kind}/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None})
+                grads.update({f"full_{kind}/loss": np.float64(full.item()), f"full_{kind}/recon": np.float64(fn(x, xhat).item()),
+                              f"full_{kind}/gc0": npy(c2[0].grad), f"full_{kind}/gc1": npy(c2[1].grad)})
+            grads.update({"full/z_in": npy(z_in), "full/low_in": npy(low_in), "full/xhat": npy(xhat), "full/w_c": np.float64(w_c)})
         dump(f"g13_step_grad_k{ix}_ch{n_ch}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z=npy(Z[0]), low=npy(Z[1]), loss=np.float64(loss.item()),
              gc0=npy(c[0].grad), gc1=npy(c[1].grad), D=np.int64(D), H=np.int64(H), W=np.int64(W), ix=np.int64(ix), S=np.int64(S),
              n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))

@@ -228,3 +228,29 @@ def test_sharded_training_step_two_ranks_on_the_gpu_path():
         assert set(grads) == set(want)
         for k in want:
             assert_close(grads[k], want[k], TOL, f"rank {rank} {k}")
+
+
+@pytest.mark.parametrize("name", ["g13_step_grad_k0_ch8", "g13_step_grad_k1_ch8"])
+@pytest.mark.parametrize("kind", ["l2", "l1"])
+def test_full_training_loss_backward_golden(name, kind):
+    """The reference's default training loss of a flow step -- 0.40984 * mse(gt, xhat) + 0.59016 * NLL with xhat from the
+    inverse pass on a sampled z (CWFA.py:905-911,952-987; main.py:43,107), and its L1 variant -- forward values and
+    every gradient against the reference's own autograd (fixture g13 `grad_l2/`, `grad_l1/`)."""
+    from cwfa_amd import training
+    fx, g = _golden_step(name)
+    cu = lambda k: torch.from_numpy(fx[k]).cuda()       # noqa: E731
+    c = [cu("c0"), cu("c1")]
+    out = training.step_backward(g, cu("x"), c, low=cu("full/low_in"), z=cu("full/z_in"), cond_weight=float(fx["full/w_c"]),
+                                 loss_func=kind.upper(), want_cond_grads=True)
+    if kind == "l1":
+        pass                                            # xhat is the same reconstruction for both losses
+    assert_close(out["xhat"], fx["full/xhat"], TOL, "xhat")
+    for key, ref in (("full_loss", f"full_{kind}/loss"), ("recon", f"full_{kind}/recon")):
+        assert abs(float(out[key]) - float(fx[ref])) <= 1e-5 * abs(float(fx[ref])), key
+    want = {k[len(f"grad_{kind}/"):]: v for k, v in fx.items() if k.startswith(f"grad_{kind}/")}
+    got = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
+    assert set(got) == set(want) and len(want) == 80
+    for k in sorted(want):
+        assert_close(got[k], want[k], TOL if kind == "l2" else 5e-4, k)
+    assert_close(out["cond_grads"][0], fx[f"full_{kind}/gc0"], TOL if kind == "l2" else 5e-4, "d loss / d omega")
+    assert_close(out["cond_grads"][1], fx[f"full_{kind}/gc1"], TOL if kind == "l2" else 5e-4, "d loss / d mean detail")
