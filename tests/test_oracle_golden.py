@@ -227,3 +227,28 @@ def test_step_gradients_vs_reference_autograd(name):
         assert_close(sd[k].grad, fx["grad/" + k], 1e-4, k)
     assert_close(c[0].grad, fx["gc0"], 1e-4, "d loss / d omega")
     assert_close(c[1].grad, fx["gc1"], 1e-4, "d loss / d mean detail")
+
+
+@pytest.mark.parametrize("name", ["g13_step_grad_k0_ch8", "g13_step_grad_k1_ch8"])
+@pytest.mark.parametrize("kind", ["l2", "l1"])
+def test_full_training_loss_gradients_vs_reference_autograd(name, kind):
+    """The default training loss of a flow step (0.40984 * mse / l1(gt, xhat) + 0.59016 * NLL, CWFA.py:905-911,952-987)
+    through the oracle's inverse + forward pass against the reference's autograd."""
+    import torch.nn.functional as F
+    fx = load_golden(name)
+    sd = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point else v) for k, v in sd_of(fx).items()}
+    axes = {i: 1 for i in range(3, 12, 2)}
+    axes.update(_axes(fx))
+    x = T(fx["x"])
+    c = [T(fx["c0"]).requires_grad_(), T(fx["c1"]).requires_grad_()]
+    w_c = float(fx["full/w_c"])
+    xhat, _ = O.flow_step(sd, (T(fx["full/z_in"]), T(fx["full/low_in"])), c, True, axes, "CAT")
+    assert_close(xhat, fx["full/xhat"], 1e-5, "xhat")
+    (z, low), jac = O.flow_step(sd, x, c, False, axes, "CAT")
+    recon = (F.mse_loss if kind == "l2" else F.l1_loss)(x, xhat)
+    full = w_c * recon + (1 - w_c) * (0.5 * torch.norm(z) ** 2 - jac.mean()) / x.numel()
+    assert abs(float(full) - float(fx[f"full_{kind}/loss"])) <= 1e-5 * abs(float(fx[f"full_{kind}/loss"]))
+    full.backward()
+    for k in [k[len(f"grad_{kind}/"):] for k in fx if k.startswith(f"grad_{kind}/")]:
+        assert_close(sd[k].grad, fx[f"grad_{kind}/" + k], 1e-4 if kind == "l2" else 5e-4, k)
+    assert_close(c[0].grad, fx[f"full_{kind}/gc0"], 5e-4, "d loss / d omega")
