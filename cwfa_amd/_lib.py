@@ -73,6 +73,12 @@ SIGNATURES = {
     "cwfa_conv2d_wgrad_workspace_bytes": (i64, [i, i, i, i, i, i]),
     "cwfa_conv2d_wgrad_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, i64, i64, f, p]),
     "cwfa_elu_bwd_f32": (i, [p, p, p, p, i, i64, i64, i64, i64, i64, p]),
+    "cwfa_conv3d_hidden_fwd_f32": (i, [p, p, p, p, i, i, i, i, i, p]),
+    "cwfa_conv3d_hidden_bwd_f32": (i, [p, p, p, p, p, p, i, i, i, i, i, p]),
+    "cwfa_conv3d_input_bwd_f32": (i, [p, p, p, i, i, i, i, i, p]),
+    "cwfa_conv3d_wgrad_workspace_bytes": (i64, [i, i, i, i]),
+    "cwfa_conv3d_wgrad_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, i, f, p]),
+    "cwfa_prelu_bwd_f32": (i, [p, p, p, p, p, i, i64, i64, i64, i64, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),

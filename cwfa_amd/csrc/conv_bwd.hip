@@ -331,3 +331,276 @@ extern "C" int cwfa_elu_bwd_f32(const float* g, const float* a, const float* add
     CWFA_LAUNCH_CHECK("cwfa_elu_bwd_f32");
     return CWFA_OK;
 }
+
+// =====================================================================================================================
+// Backward of the condition net's 3-D stage  y = W2 * PReLU(W1 * x + b1) + b2  (Conv3d 1 -> K -> 1 over (H, W, depth),
+// networks.py:221-225,239; weight index (ih*3 + iw)*3 + id as in conv3d.hip) and of its 2-D PReLUs -- the autograd of the
+// reference's `optimizer_cond` path (CWFA.py:1008-1012).  The K-channel hidden volume is materialised here (q and m,
+// B*K*D*H*W floats each: 1.6 GB at 512 x 512 x 48, K = 32 -- small against 288 GB) and the pieces are separate passes:
+//   conv3d_hidden_fwd :  q = W1 * x + b1                                   (VALU, 27 K FMAs per voxel)
+//   conv3d_hidden_bwd :  m = (W2^T * dy) . PReLU'(q),  dalpha += sum (W2^T * dy) . min(q, 0)
+//   conv3d_wgrad      :  dW[k][tap] = sum_p A[k][p] * src[p +- (tap - 1)]     (fp32 MFMA GEMM, M = K <= 32, N = 27 taps + 1
+//                        ones column for the bias, reduction over voxels; operands straight from global memory)
+//   conv3d_input_bwd  :  dx = sum_k W1[k]^T * m[k]
+// =====================================================================================================================
+namespace {
+
+struct Vox {
+    int d, y, x;
+};
+
+// neighbour offsets of the 27 taps around voxel (d,y,x): sign +1 -> p + (tap - 1), sign -1 -> p - (tap - 1); byte offset
+// inside one [D][H][W] volume, or the out-of-range marker for taps that fall into the zero padding
+__device__ __forceinline__ void tap_offsets(Vox v, int D, int H, int W, int sign, unsigned (&off)[27]) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int ih = t / 9, iw = (t / 3) % 3, id = t % 3;
+        const int y = v.y + sign * (ih - 1), x = v.x + sign * (iw - 1), d = v.d + sign * (id - 1);
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W && d >= 0 && d < D;
+        off[t] = ok ? (unsigned)(((int64_t)d * H + y) * W + x) * 4u : 0x80000000u;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3d_hidden_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, float* __restrict__ q, int D, int H,
+                                                                int W, int K) {
+    const int64_t vol = (int64_t)D * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vol) return;
+    const int b = blockIdx.y;
+    const Vox v{(int)(i / ((int64_t)H * W)), (int)((i / W) % H), (int)(i % W)};
+    unsigned off[27];
+    tap_offsets(v, D, H, W, +1, off);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)b * vol), 0, (int)(vol * 4), 0x00020000);
+    float nb[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) nb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[t], 0, 0));
+    float* qb = q + (int64_t)b * K * vol + i;
+    for (int k = 0; k < K; ++k) {
+        float acc = b1[k];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc = fmaf(w1[k * 27 + t], nb[t], acc);
+        qb[(int64_t)k * vol] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3d_hidden_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w2,
+                                                                const float* __restrict__ q, const float* __restrict__ alpha_p,
+                                                                float* __restrict__ m, double* __restrict__ dalpha, int D, int H,
+                                                                int W, int K) {
+    __shared__ double red[16];
+    const int64_t vol = (int64_t)D * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const float alpha = *alpha_p;
+    float da = 0.f;
+    if (i < vol) {
+        const Vox v{(int)(i / ((int64_t)H * W)), (int)((i / W) % H), (int)(i % W)};
+        unsigned off[27];
+        tap_offsets(v, D, H, W, -1, off);
+        const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (int64_t)b * vol), 0, (int)(vol * 4), 0x00020000);
+        float nb[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) nb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off[t], 0, 0));
+        const float* qb = q + (int64_t)b * K * vol + i;
+        float* mb = m + (int64_t)b * K * vol + i;
+        for (int k = 0; k < K; ++k) {
+            float dh = 0.f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) dh = fmaf(w2[k * 27 + t], nb[t], dh);
+            const float qv = qb[(int64_t)k * vol];
+            mb[(int64_t)k * vol] = qv > 0.f ? dh : alpha * dh;
+            da += qv > 0.f ? 0.f : dh * qv;
+        }
+    }
+    if (dalpha) {
+        const double tot = cwfa_block_sum((double)da, red);
+        if (threadIdx.x == 0) atomicAdd(dalpha, tot);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3d_input_bwd_kernel(const float* __restrict__ m, const float* __restrict__ w1,
+                                                               float* __restrict__ dx, int D, int H, int W, int K) {
+    const int64_t vol = (int64_t)D * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vol) return;
+    const int b = blockIdx.y;
+    const Vox v{(int)(i / ((int64_t)H * W)), (int)((i / W) % H), (int)(i % W)};
+    unsigned off[27];
+    tap_offsets(v, D, H, W, -1, off);
+    // one descriptor over the K hidden volumes of this sample (< 2 GiB, checked by the host); the channel moves through the
+    // scalar offset and the padding marker 0x80000000 is out of range whichever way the offsets are summed
+    const auto rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m + (int64_t)b * K * vol), 0, (int)((int64_t)K * vol * 4),
+                                                      0x00020000);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int so = (int)((int64_t)k * vol * 4);
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+            acc = fmaf(w1[k * 27 + t], __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, off[t], so, 0)), acc);
+    }
+    dx[(int64_t)b * vol + i] = acc;
+}
+
+// GEMM over voxels on the matrix cores: D[k][tap] += A[k][p] * src[p + sign*(tap - 1)];  column 27 multiplies ones (the
+// bias gradient of the convolution whose output gradient is A).  A wave owns runs of 64 voxels along x (32 k-steps of two
+// voxels); lane (l31, kh) feeds row k = l31 of A and column tap = l31 of the shifted source, both straight from global
+// memory (consecutive steps walk consecutive addresses: cache hits).  Each wave writes its 32 x 32 partial; the partials are
+// summed in a fixed order by wgrad_reduce_kernel.
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ src,
+                                                           const float* __restrict__ alpha_p, float* __restrict__ part, int B, int D,
+                                                           int H, int W, int K, int sign, int want_bias) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int64_t HW = (int64_t)H * W, vol = (int64_t)D * HW;
+    const int chunks = (W + 63) / 64;
+    const int64_t items = (int64_t)B * D * H * chunks;
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const int ih = l31 / 9, iw = (l31 / 3) % 3, id = l31 % 3;       // this lane's tap (l31 < 27)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t it = wave; it < items; it += nwaves) {
+        const int ch = (int)(it % chunks);
+        const int64_t row = it / chunks;
+        const int y = (int)(row % H), d = (int)((row / H) % D), b = (int)(row / ((int64_t)H * D));
+        const int x0 = ch * 64;
+        const float* ap = a + ((int64_t)b * K + l31) * vol + (int64_t)d * HW + (int64_t)y * W;
+        const int sy = y + sign * (ih - 1), sd = d + sign * (id - 1), sxo = sign * (iw - 1);
+        const bool row_ok = l31 < 27 && sy >= 0 && sy < H && sd >= 0 && sd < D;
+        const float* sp = src + (int64_t)b * vol + (int64_t)(row_ok ? sd : 0) * HW + (int64_t)(row_ok ? sy : 0) * W;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int x = x0 + 2 * s + kh;
+            float av = 0.f, bv = 0.f;
+            if (x < W) {
+                if (l31 < K) {
+                    av = ap[x];
+                    if (alpha_p) av = av > 0.f ? av : alpha * av;
+                }
+                const int sx = x + sxo;
+                if (row_ok && sx >= 0 && sx < W) bv = sp[sx];
+                if (l31 == 27 && want_bias) bv = 1.f;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    float* out = part + (int64_t)wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[acc_row(r, kh) * 32 + l31] = acc[r];
+}
+
+// PReLU backward from the layer's OUTPUT o = PReLU(q), single alpha > 0:  y = g * (o > 0 ? 1 : alpha),
+// dalpha += sum g * min(q, 0) with q = o / alpha where o < 0
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ o,
+                                                        const float* __restrict__ alpha_p, float* __restrict__ y,
+                                                        double* __restrict__ dalpha, int64_t n, int64_t g_bs, int64_t o_bs, int64_t y_bs) {
+    __shared__ double red[16];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const float alpha = *alpha_p;
+    float da = 0.f;
+    if (i < n) {
+        const float gv = g[b * g_bs + i], ov = o[b * o_bs + i];
+        y[b * y_bs + i] = ov > 0.f ? gv : alpha * gv;
+        da = ov > 0.f ? 0.f : gv * (ov / alpha);
+    }
+    if (dalpha) {
+        const double tot = cwfa_block_sum((double)da, red);
+        if (threadIdx.x == 0) atomicAdd(dalpha, tot);
+    }
+}
+
+int check_c3(const char* name, int B, int D, int H, int W, int K) {
+    CWFA_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && K > 0 && B <= 65535, CWFA_E_SHAPE, "%s: bad shape", name);
+    CWFA_REQUIRE((int64_t)D * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "%s: volume too large for 32-bit offsets", name);
+    CWFA_REQUIRE((int64_t)K * D * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "%s: hidden volume too large for 32-bit offsets", name);
+    return CWFA_OK;
+}
+
+}  // namespace
+
+extern "C" int cwfa_conv3d_hidden_fwd_f32(const float* x, const float* w1, const float* b1, float* q, int B, int D, int H, int W,
+                                          int K, void* stream) {
+    CWFA_REQUIRE(x && w1 && b1 && q, CWFA_E_INVAL, "cwfa_conv3d_hidden_fwd_f32: null pointer");
+    int rc = check_c3("cwfa_conv3d_hidden_fwd_f32", B, D, H, W, K);
+    if (rc) return rc;
+    if (B == 0) return CWFA_OK;
+    const int64_t vol = (int64_t)D * H * W;
+    hipLaunchKernelGGL(conv3d_hidden_fwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, w1, b1, q,
+                       D, H, W, K);
+    CWFA_LAUNCH_CHECK("cwfa_conv3d_hidden_fwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_conv3d_hidden_bwd_f32(const float* dy, const float* w2, const float* q, const float* alpha, float* m,
+                                          double* dalpha, int B, int D, int H, int W, int K, void* stream) {
+    CWFA_REQUIRE(dy && w2 && q && alpha && m, CWFA_E_INVAL, "cwfa_conv3d_hidden_bwd_f32: null pointer");
+    int rc = check_c3("cwfa_conv3d_hidden_bwd_f32", B, D, H, W, K);
+    if (rc) return rc;
+    if (B == 0) return CWFA_OK;
+    const int64_t vol = (int64_t)D * H * W;
+    hipLaunchKernelGGL(conv3d_hidden_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, dy, w2, q,
+                       alpha, m, dalpha, D, H, W, K);
+    CWFA_LAUNCH_CHECK("cwfa_conv3d_hidden_bwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_conv3d_input_bwd_f32(const float* m, const float* w1, float* dx, int B, int D, int H, int W, int K, void* stream) {
+    CWFA_REQUIRE(m && w1 && dx, CWFA_E_INVAL, "cwfa_conv3d_input_bwd_f32: null pointer");
+    int rc = check_c3("cwfa_conv3d_input_bwd_f32", B, D, H, W, K);
+    if (rc) return rc;
+    if (B == 0) return CWFA_OK;
+    const int64_t vol = (int64_t)D * H * W;
+    hipLaunchKernelGGL(conv3d_input_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, m, w1, dx, D,
+                       H, W, K);
+    CWFA_LAUNCH_CHECK("cwfa_conv3d_input_bwd_f32");
+    return CWFA_OK;
+}
+
+static int c3_wgrad_blocks(int B, int D, int H, int W) {
+    const int64_t items = (int64_t)B * D * H * ((W + 63) / 64);
+    int64_t blocks = (items + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int64_t cwfa_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 4096;
+    return (int64_t)c3_wgrad_blocks(B, D, H, W) * 4 * 1024 * 4;
+}
+
+/* a [B,K,D,H,W] (K <= 32), src [B,D,H,W]; out32 [32][32] floats: out32[k][tap] = beta*out32 + sum_p act(a[k][p]) *
+ * src[p + sign*(tap-1)] for tap < 27, out32[k][27] = sum_p act(a[k][p]) if want_bias; act = PReLU(alpha) when alpha != NULL */
+extern "C" int cwfa_conv3d_wgrad_f32(const float* a, const float* src, const float* alpha, float* out32, void* workspace, int B,
+                                     int D, int H, int W, int K, int sign, int want_bias, float beta, void* stream) {
+    CWFA_REQUIRE(a && src && out32 && workspace, CWFA_E_INVAL, "cwfa_conv3d_wgrad_f32: null pointer");
+    CWFA_REQUIRE(K <= 32, CWFA_E_SHAPE, "cwfa_conv3d_wgrad_f32: K = %d hidden channels (at most 32 are built)", K);
+    CWFA_REQUIRE(sign == 1 || sign == -1, CWFA_E_INVAL, "cwfa_conv3d_wgrad_f32: sign must be +1 or -1");
+    int rc = check_c3("cwfa_conv3d_wgrad_f32", B, D, H, W, K);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int nparts = 0;
+    if (B > 0) {
+        const int blocks = c3_wgrad_blocks(B, D, H, W);
+        nparts = blocks * 4;
+        hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(blocks), dim3(256), 0, st, a, src, alpha, reinterpret_cast<float*>(workspace), B, D,
+                           H, W, K, sign, want_bias);
+        CWFA_LAUNCH_CHECK("cwfa_conv3d_wgrad_f32");
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), out32, (int64_t)1024,
+                       nparts, beta);
+    CWFA_LAUNCH_CHECK("cwfa_conv3d_wgrad_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_prelu_bwd_f32(const float* g, const float* o, const float* alpha, float* y, double* dalpha, int B, int64_t n,
+                                  int64_t g_bs, int64_t o_bs, int64_t y_bs, void* stream) {
+    CWFA_REQUIRE(g && o && alpha && y, CWFA_E_INVAL, "cwfa_prelu_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && n >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_prelu_bwd_f32: bad shape");
+    if (B == 0 || n == 0) return CWFA_OK;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, g, o, alpha, y, dalpha,
+                       n, g_bs, o_bs, y_bs);
+    CWFA_LAUNCH_CHECK("cwfa_prelu_bwd_f32");
+    return CWFA_OK;
+}

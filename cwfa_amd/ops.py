@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "chain_inv_bwd", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -486,6 +486,51 @@ def elu_bwd(g, a, add=None, out=None):
         raise ValueError("elu_bwd: `out` must have contiguous planes")
     check(L.cwfa_elu_bwd_f32(_p(g), _p(a), _p(add), _p(out), B, n, gbs, abs_, addbs, obs, _stream()), "elu_bwd")
     return out
+
+
+def prelu_bwd(g, o, alpha, dalpha=None, out=None):
+    """g * PReLU'(q) from the activation output o (single alpha > 0); ``dalpha`` (float64[1]) accumulates sum g*min(q,0)."""
+    L = _lib.lib()
+    g, gbs = planes(g, "g")
+    o, obs = planes(o, "o")
+    B, n = g.shape[0], g[0].numel()
+    if out is None:
+        out = torch.empty(tuple(g.shape), dtype=torch.float32, device=g.device)
+    o2, ybs = planes(out, "out")
+    if o2.data_ptr() != out.data_ptr():
+        raise ValueError("prelu_bwd: `out` must have contiguous planes")
+    check(L.cwfa_prelu_bwd_f32(_p(g), _p(o), _p(_dev(alpha)), _p(out), _p(dalpha), B, n, gbs, obs, ybs, _stream()), "prelu_bwd")
+    return out
+
+
+def conv3d_1k1_backward(x, dy, w1, b1, alpha, w2, want_input_grad=True):
+    """Backward of ``conv3d_1k1`` (y = W2 * PReLU(W1 * x + b1) + b2): returns (dx or None, dW1, db1, dW2, db2, dalpha[float64 1])."""
+    L = _lib.lib()
+    x = _dev(x, "x").contiguous()
+    dy = _dev(dy, "dy").contiguous()
+    B, D, H, W = x.shape
+    K = w1.shape[0]
+    w1c, w2c = _dev(w1).detach().contiguous(), _dev(w2).detach().contiguous()
+    st = _stream()
+    q = torch.empty((B, K, D, H, W), dtype=torch.float32, device=x.device)
+    m = torch.empty_like(q)
+    dalpha = torch.zeros(1, dtype=torch.float64, device=x.device)
+    ws = torch.empty(L.cwfa_conv3d_wgrad_workspace_bytes(B, D, H, W), dtype=torch.uint8, device=x.device)
+    g2 = torch.empty(32, 32, dtype=torch.float32, device=x.device)
+    g1 = torch.empty(32, 32, dtype=torch.float32, device=x.device)
+    check(L.cwfa_conv3d_hidden_fwd_f32(_p(x), _p(w1c), _p(_dev(b1)), _p(q), B, D, H, W, K, st), "conv3d_hidden_fwd")
+    check(L.cwfa_conv3d_wgrad_f32(_p(q), _p(dy), _p(_dev(alpha)), _p(g2), _p(ws), B, D, H, W, K, -1, 0, 0.0, st), "conv3d_wgrad")
+    check(L.cwfa_conv3d_hidden_bwd_f32(_p(dy), _p(w2c), _p(q), _p(_dev(alpha)), _p(m), _p(dalpha), B, D, H, W, K, st), "conv3d_hidden_bwd")
+    check(L.cwfa_conv3d_wgrad_f32(_p(m), _p(x), None, _p(g1), _p(ws), B, D, H, W, K, 1, 1, 0.0, st), "conv3d_wgrad")
+    dx = None
+    if want_input_grad:
+        dx = torch.empty_like(x)
+        check(L.cwfa_conv3d_input_bwd_f32(_p(m), _p(w1c), _p(dx), B, D, H, W, K, st), "conv3d_input_bwd")
+    dW1 = g1[:K, :27].reshape(K, 1, 3, 3, 3).contiguous()
+    db1 = g1[:K, 27].contiguous()
+    dW2 = g2[:K, :27].reshape(1, K, 3, 3, 3).contiguous()
+    db2 = sample_stats(dy.reshape(1, -1, 1, 1))[0:1].to(torch.float32)
+    return dx, dW1, db1, dW2, db2, dalpha
 
 
 def conv3d_1k1(x, w1, b1, alpha, w2, b2):

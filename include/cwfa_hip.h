@@ -317,6 +317,28 @@ int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* db,
 int cwfa_elu_bwd_f32(const float* g, const float* a, const float* add, float* y, int B, int64_t n, int64_t g_bs, int64_t a_bs,
                      int64_t add_bs, int64_t y_bs, void* stream);
 
+/* Backward of the condition net's 3-D stage y = W2 * PReLU(W1 * x + b1) + b2 (Conv3d 1 -> K -> 1 over (H, W, depth),
+ * networks.py:221-225,239; x, y, dy: [B,D,H,W] with the depth axis as channel axis; w1 [K,1,3,3,3], w2 [1,K,3,3,3]) in
+ * separate passes over a materialised hidden volume q / m [B,K,D,H,W]:
+ *   hidden_fwd: q = W1 * x + b1;   hidden_bwd: m = (W2^T * dy) . PReLU'(q), dalpha (nullable, double[1]) += sum (W2^T*dy).min(q,0);
+ *   input_bwd:  dx = sum_k W1[k]^T * m[k];
+ *   wgrad: out32[k][tap] = beta*out32 + sum_p act(a[k][p]) * src[p + sign*(tap-1)] (tap < 27; column 27 = sum_p act(a[k][p])
+ *          when want_bias), act = PReLU(alpha) if alpha != NULL -- dW2 = wgrad(a = q, alpha, src = dy, sign = -1),
+ *          dW1 | db1 = wgrad(a = m, src = x, sign = +1, want_bias).  K <= 32; out32 is a [32][32] float buffer. */
+int cwfa_conv3d_hidden_fwd_f32(const float* x, const float* w1, const float* b1, float* q, int B, int D, int H, int W, int K,
+                               void* stream);
+int cwfa_conv3d_hidden_bwd_f32(const float* dy, const float* w2, const float* q, const float* alpha, float* m, double* dalpha,
+                               int B, int D, int H, int W, int K, void* stream);
+int cwfa_conv3d_input_bwd_f32(const float* m, const float* w1, float* dx, int B, int D, int H, int W, int K, void* stream);
+int64_t cwfa_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W);
+int cwfa_conv3d_wgrad_f32(const float* a, const float* src, const float* alpha, float* out32, void* workspace, int B, int D, int H,
+                          int W, int K, int sign, int want_bias, float beta, void* stream);
+
+/* PReLU backward (single alpha > 0) from the layer output o = PReLU(q):  y = g * (o > 0 ? 1 : alpha),
+ * dalpha (nullable, double[1]) += sum g * min(q, 0).  n elements per sample, batch strides in elements. */
+int cwfa_prelu_bwd_f32(const float* g, const float* o, const float* alpha, float* y, double* dalpha, int B, int64_t n, int64_t g_bs,
+                       int64_t o_bs, int64_t y_bs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

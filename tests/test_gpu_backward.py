@@ -254,3 +254,50 @@ def test_full_training_loss_backward_golden(name, kind):
         assert_close(got[k], want[k], TOL if kind == "l2" else 5e-4, k)
     assert_close(out["cond_grads"][0], fx[f"full_{kind}/gc0"], TOL if kind == "l2" else 5e-4, "d loss / d omega")
     assert_close(out["cond_grads"][1], fx[f"full_{kind}/gc1"], TOL if kind == "l2" else 5e-4, "d loss / d mean detail")
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 11, 5), (1, 12, 20, 70, 32), (1, 3, 5, 130, 8), (3, 1, 4, 4, 2)])   # (B, D, H, W, K)
+def test_conv3d_stage_backward_vs_autograd(cfg):
+    """Conv3d(1->K) -> PReLU -> Conv3d(K->1) over (H, W, depth) (networks.py:221-225,239): every gradient against float64
+    autograd -- input, both filter banks, both biases, the PReLU slope."""
+    from cwfa_amd import ops
+    B, D, H, W, K = cfg
+    g0 = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, D, H, W, generator=g0)
+    dy = torch.randn(B, D, H, W, generator=g0)
+    w1 = torch.randn(K, 1, 3, 3, 3, generator=g0) * 0.3
+    b1 = torch.randn(K, generator=g0) * 0.1
+    w2 = torch.randn(1, K, 3, 3, 3, generator=g0) * 0.3
+    b2 = torch.randn(1, generator=g0)
+    alpha = torch.tensor([0.25])
+    leaves = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2, alpha)]
+    xd, w1d, b1d, w2d, b2d, ad = leaves
+    vol = xd.permute(0, 2, 3, 1).unsqueeze(1)                                  # [B,1,H,W,D] as networks.py:239
+    y = F.conv3d(F.prelu(F.conv3d(vol, w1d, b1d, padding=1), ad), w2d, b2d, padding=1)[:, 0].permute(0, 3, 1, 2)
+    (y * dy.double()).sum().backward()
+    with torch.no_grad():
+        got_y = ops.conv3d_1k1(x.cuda(), w1.cuda(), b1.cuda(), alpha.cuda(), w2.cuda(), b2.cuda())
+    assert_close(got_y, y.detach(), 1e-5, "forward")
+    dx, dW1, db1, dW2, db2, dalpha = ops.conv3d_1k1_backward(x.cuda(), dy.cuda(), w1.cuda(), b1.cuda(), alpha.cuda(), w2.cuda())
+    from conftest import rel_err
+    bad = []
+    for name, got, ref in (("dx", dx, xd.grad), ("dW1", dW1, w1d.grad), ("db1", db1, b1d.grad), ("dW2", dW2, w2d.grad),
+                           ("db2", db2, b2d.grad), ("dalpha", dalpha, ad.grad)):
+        e = max(rel_err(got, ref))
+        if not e <= TOL:
+            bad.append((name, e))
+    assert not bad, (cfg, bad)
+
+
+def test_prelu_backward():
+    from cwfa_amd import ops
+    g0 = torch.Generator().manual_seed(8)
+    q = torch.randn(2, 5, 7, 9, generator=g0, dtype=torch.float64, requires_grad=True)
+    a = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    o = F.prelu(q, a)
+    gup = torch.randn(2, 5, 7, 9, generator=g0)
+    o.backward(gup.double())
+    dalpha = torch.zeros(1, dtype=torch.float64, device="cuda")
+    got = ops.prelu_bwd(gup.cuda(), o.detach().float().cuda(), a.detach().float().cuda(), dalpha)
+    assert_close(got, q.grad, 1e-6, "prelu backward")
+    assert_close(dalpha, a.grad, 1e-5, "d alpha")
