@@ -17,8 +17,9 @@ rank scales its local gradient by the global 1/numel and the ranks' gradients ar
 packs them into a few large flat buckets (default 64 MiB: the flow parameters of one step are 13.7 MB, so one message)
 and issues one all-reduce per bucket (RCCL over xGMI on MI355X; gloo in the CPU test).
 
-Scope of this slice: gradients of the flow step's own parameters (the reference's ``optimizer``) and dL/d(conditions);
-the condition networks' backward (``optimizer_cond``: Conv3d / LRNN) is not built yet.
+Scope: gradients of a flow step's own parameters (the reference's ``optimizer``) and of its condition net
+(``optimizer_cond`` for the flow steps: ``cond_forward_train`` / ``cond_backward``); the LRNN (the last step's
+condition net: UNet + ConvNeXt, trained with an L2 loss) has no backward here yet.
 """
 from typing import Dict, List, Optional, Sequence
 
@@ -26,7 +27,8 @@ import torch
 
 from . import ops
 
-__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "allreduce_gradients", "sgd_step"]
+__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "cond_forward_train", "cond_backward", "allreduce_gradients",
+           "sgd_step"]
 
 
 class _Tape:
@@ -233,6 +235,63 @@ def step_backward(graph, gt, c, low=None, z=None, cond_weight=0.40984, loss_func
         cond_grads = [cond_grads[id(t)] for t in c]
     full = (1.0 - w_c) * nll + (w_c * recon_mean if recon else 0.0)
     return {"full_loss": full, "nll": nll, "recon": recon_mean, "Z": (zf, lowf), "xhat": xhat, "cond_grads": cond_grads}
+
+
+class _CondTape:
+    __slots__ = ("block", "x", "o1", "o")
+
+    def __init__(self, block, x, o1, o):
+        self.block, self.x, self.o1, self.o = block, x, o1, o
+
+
+def cond_forward_train(cond_net, views):
+    """``cond_network.forward`` (networks.py:165-242, eval mode as CWFA.py:527-528 keeps the flow steps' condition nets:
+    Dropout3d off) with the two 2-D maps the backward needs kept.  Returns (omega, tape)."""
+    blk = cond_net.subnetworks[0]
+    if blk.training:
+        raise NotImplementedError("cond_forward_train: train-mode Dropout3d is not on the HIP path (the reference keeps the "
+                                  "flow steps' condition nets in eval mode, CWFA.py:527-528)")
+    a = blk.relu.weight
+    P = blk._packed.get
+    c1, c2, ds = blk.conv1[0], blk.conv2[0], blk.downsample[0]
+    o1 = ops.conv2d(views, P(c1), bias=c1.bias, act="prelu", prelu_alpha=a)
+    r = ops.conv2d(views, P(ds), bias=ds.bias)
+    o = ops.conv2d(o1, P(c2), bias=c2.bias, residual=r, act2="prelu", prelu_alpha=a)
+    k1, k2 = blk.conv3d[0], blk.conv3d[3]
+    omega = ops.conv3d_1k1(o, k1.weight, k1.bias, a, k2.weight, k2.bias)
+    return omega, _CondTape(blk, views, o1, o)
+
+
+def _acc(param, g):
+    g = g.to(param.dtype).reshape(param.shape)
+    if param.grad is None:
+        param.grad = g.clone()
+    else:
+        param.grad.add_(g)
+
+
+def cond_backward(tape, g_omega):
+    """Backward of ``cond_forward_train`` from dL/d(omega): accumulates the .grad of the three 2-D convolutions, the two
+    Conv3d layers and the (shared, single-parameter) PReLU slope -- the reference's ``optimizer_cond`` parameters
+    (CWFA.py:1008-1012).  The slope must be positive (the pre-activations are recovered from the outputs)."""
+    blk = tape.block
+    a = blk.relu.weight
+    if not float(a.detach()) > 0.0:
+        raise NotImplementedError("cond_backward: PReLU slope <= 0 (pre-activations are recovered from the layer outputs)")
+    c1, c2, ds = blk.conv1[0], blk.conv2[0], blk.downsample[0]
+    k1, k2 = blk.conv3d[0], blk.conv3d[3]
+    g_o, dW1, db1, dW2, db2, dalpha = ops.conv3d_1k1_backward(tape.o, g_omega, k1.weight, k1.bias, a, k2.weight)
+    _acc(k1.weight, dW1)
+    _acc(k1.bias, db1)
+    _acc(k2.weight, dW2)
+    _acc(k2.bias, db2)
+    g_pre = ops.prelu_bwd(g_o, tape.o, a, dalpha, out=g_o)           # o = PReLU(conv2(o1) + downsample(x))
+    _conv_param_grads(c2, tape.o1, g_pre)
+    _conv_param_grads(ds, tape.x, g_pre)
+    g_o1 = ops.conv2d(g_pre, _packT(c2))
+    ops.prelu_bwd(g_o1, tape.o1, a, dalpha, out=g_o1)               # o1 = PReLU(conv1(x))
+    _conv_param_grads(c1, tape.x, g_o1)
+    _acc(a, dalpha.to(torch.float32))
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):

@@ -419,6 +419,25 @@ def gen_step_grad():
                 grads.update({f"full_{kind}/loss": np.float64(full.item()), f"full_{kind}/recon": np.float64(fn(x, xhat).item()),
                               f"full_{kind}/gc0": npy(c2[0].grad), f"full_{kind}/gc1": npy(c2[1].grad)})
             grads.update({"full/z_in": npy(z_in), "full/low_in": npy(low_in), "full/xhat": npy(xhat), "full/w_c": np.float64(w_c)})
+            # ... and with the condition computed by the step's condition net (eval mode, CWFA.py:527-528,893), so that the
+            # gradients reach its parameters too (`optimizer_cond`, CWFA.py:1008-1012)
+            cond_net.eval()
+            with torch.no_grad():
+                for p in cond_net.parameters():
+                    p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            views = torch.randn(B, 29, H, W, generator=g)
+            for p in list(inn.parameters()) + list(cond_net.parameters()):
+                p.grad = None
+            om = cond_net(views)[-1]
+            c3 = [om, c[1].detach()]
+            xhat3, _ = inn([z_in, low_in], c=c3, rev=True)
+            Z3, ld3 = inn(x, c=c3)
+            full3 = w_c * F.mse_loss(x, xhat3) + (1 - w_c) * (0.5 * torch.norm(Z3[0]) ** 2 - ld3.mean()) / xhat3.numel()
+            full3.backward()
+            grads.update({"cond/views": npy(views), "cond/omega": npy(om), "cond/loss": np.float64(full3.item())})
+            grads.update({"condgrad/" + k: npy(p.grad) for k, p in cond_net.named_parameters() if p.grad is not None})
+            grads.update({"flowgrad_cond/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None})
+            grads.update(sd_arrays(cond_net, "condsd/"))
         dump(f"g13_step_grad_k{ix}_ch{n_ch}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z=npy(Z[0]), low=npy(Z[1]), loss=np.float64(loss.item()),
              gc0=npy(c[0].grad), gc1=npy(c[1].grad), D=np.int64(D), H=np.int64(H), W=np.int64(W), ix=np.int64(ix), S=np.int64(S),
              n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))

@@ -301,3 +301,39 @@ def test_prelu_backward():
     got = ops.prelu_bwd(gup.cuda(), o.detach().float().cuda(), a.detach().float().cuda(), dalpha)
     assert_close(got, q.grad, 1e-6, "prelu backward")
     assert_close(dalpha, a.grad, 1e-5, "d alpha")
+
+
+@pytest.mark.parametrize("name", ["g13_step_grad_k0_ch8", "g13_step_grad_k1_ch8"])
+def test_training_loss_backward_into_the_condition_net_golden(name):
+    """The default training loss with the condition computed by the step's own condition net (eval mode, CWFA.py:527-528,
+    893): gradients of the condition net's parameters (`optimizer_cond`) and of the flow step against the reference's
+    autograd (fixture g13 `condgrad/`, `flowgrad_cond/`)."""
+    from conftest import sd_of
+    from cwfa_amd import networks as N, training
+    from test_host_logic import build_step
+    fx, g = _golden_step(name)
+    keep = N.networks_n_chans
+    try:
+        cond_net, _ = build_step("CAT", int(fx["ix"]), n_ch=8)
+    finally:
+        N.networks_n_chans = keep
+    cond_net.load_state_dict(sd_of(fx, "condsd/"))
+    cond_net = cond_net.eval().cuda()
+    for p in cond_net.parameters():       # the PReLU is ONE module shared by every ResidualBlock of the process (the reference's
+        p.grad = None                     # default-argument instance, networks.py:200): clear what earlier tests left on it
+    cu = lambda k: torch.from_numpy(fx[k]).cuda()       # noqa: E731
+    omega, ctape = training.cond_forward_train(cond_net, cu("cond/views"))
+    assert_close(omega, fx["cond/omega"], TOL, "omega")
+    out = training.step_backward(g, cu("x"), [omega, cu("c1")], low=cu("full/low_in"), z=cu("full/z_in"),
+                                 cond_weight=float(fx["full/w_c"]), loss_func="L2", want_cond_grads=True)
+    assert abs(float(out["full_loss"]) - float(fx["cond/loss"])) <= 1e-5 * abs(float(fx["cond/loss"]))
+    training.cond_backward(ctape, out["cond_grads"][0])
+    want = {k[len("condgrad/"):]: v for k, v in fx.items() if k.startswith("condgrad/")}
+    got = {k: p.grad for k, p in cond_net.named_parameters() if p.grad is not None}
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    for k in sorted(want):
+        assert_close(got[k], want[k], TOL, "condition net " + k)
+    wantf = {k[len("flowgrad_cond/"):]: v for k, v in fx.items() if k.startswith("flowgrad_cond/")}
+    gotf = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
+    for k in sorted(wantf):
+        assert_close(gotf[k], wantf[k], TOL, "flow step " + k)
