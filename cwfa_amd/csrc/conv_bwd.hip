@@ -496,17 +496,17 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ alpha_p, float* __restrict__ y,
                                                         double* __restrict__ dalpha, int64_t n, int64_t g_bs, int64_t o_bs, int64_t y_bs) {
     __shared__ double red[16];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     const float alpha = *alpha_p;
-    float da = 0.f;
-    if (i < n) {
+    double da = 0.0;
+    // grid-stride: a bounded number of blocks, so that the one atomic per block does not serialise the kernel
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gv = g[b * g_bs + i], ov = o[b * o_bs + i];
         y[b * y_bs + i] = ov > 0.f ? gv : alpha * gv;
-        da = ov > 0.f ? 0.f : gv * (ov / alpha);
+        da += ov > 0.f ? 0.0 : (double)(gv * (ov / alpha));
     }
     if (dalpha) {
-        const double tot = cwfa_block_sum((double)da, red);
+        const double tot = cwfa_block_sum(da, red);
         if (threadIdx.x == 0) atomicAdd(dalpha, tot);
     }
 }
@@ -599,7 +599,8 @@ extern "C" int cwfa_prelu_bwd_f32(const float* g, const float* o, const float* a
     CWFA_REQUIRE(g && o && alpha && y, CWFA_E_INVAL, "cwfa_prelu_bwd_f32: null pointer");
     CWFA_REQUIRE(B >= 0 && n >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_prelu_bwd_f32: bad shape");
     if (B == 0 || n == 0) return CWFA_OK;
-    hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, g, o, alpha, y, dalpha,
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048), B), dim3(256), 0, (hipStream_t)stream, g, o, alpha, y, dalpha,
                        n, g_bs, o_bs, y_bs);
     CWFA_LAUNCH_CHECK("cwfa_prelu_bwd_f32");
     return CWFA_OK;

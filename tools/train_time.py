@@ -46,6 +46,28 @@ def main():
             p.grad = None
         training.nll_backward(g, x, c)
 
+    cn = cond_nets[0].eval()
+    views = torch.randn(B, 29, 512, 512, generator=gen).cuda()
+    low = torch.randn(B, 48, 512, 512, generator=gen).cuda()
+    cparams = [p for p in cn.parameters() if p.requires_grad]
+
+    def full_step():                 # the reference's default training step of a flow step, condition net included
+        for p in params + cparams:
+            p.grad = None
+        omega, tape = training.cond_forward_train(cn, views)
+        out = training.step_backward(g, x, [omega, c[1]], low=low, want_cond_grads=True)
+        training.cond_backward(tape, out["cond_grads"][0])
+
+    def cond_only():
+        for p in cparams:
+            p.grad = None
+        omega, tape = training.cond_forward_train(cn, views)
+        training.cond_backward(tape, c[0])
+
+    ms_c = ev_time(cond_only, reps=3, warm=1)
+    ms_f = ev_time(full_step, reps=3, warm=1)
+    print(f"condition net (29 views -> 48 channels, Conv3d K=32) forward + backward B{B}: {ms_c:.2f} ms; full default training step "
+          f"(inverse + forward + backward of the flow step and its condition net): {ms_f:.2f} ms = {B/ms_f*1e3:.2f} volumes/s", flush=True)
     with torch.no_grad():
         fwd = ev_time(lambda: CWFA.nll_step(g, x, c), reps=5)
     ms = ev_time(step, reps=5)
