@@ -33,7 +33,7 @@ def main(out):
         for w in (1, 2, 4):
             if f"calib_read<{w}>" in k:
                 factor[4 * w] = true_kb / v
-    b = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    b = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-experiment"]
     fetch, write = run_pmc("FETCH_SIZE", b, "f"), run_pmc("WRITE_SIZE", b, "w")
     kernels = {}
     for fam, rname in bench.ROCPROF_NAMES.items():
