@@ -337,3 +337,39 @@ def test_training_loss_backward_into_the_condition_net_golden(name):
     gotf = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
     for k in sorted(wantf):
         assert_close(gotf[k], wantf[k], TOL, "flow step " + k)
+
+
+def test_full_size_directional_derivative():
+    """BASELINE.json configs[3] per-rank shape (512x512x96, the finest flow step, 64 internal channels) -- too large for the
+    CPU oracle's autograd, so a size-independent property: along a random direction v in parameter space the central
+    difference of the loss, (L(theta + e v) - L(theta - e v)) / 2e, equals <grad, v> from step_backward."""
+    from cwfa_amd import CWFA, training
+    torch.manual_seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, with_lrnn=False, device="cuda")
+    g = conv_inn[0].train()
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 96, 512, 512, generator=gen).cuda()
+    c = [torch.randn(1, 48, 512, 512, generator=gen).cuda(), (0.1 * torch.randn(1, 48, 512, 512, generator=gen)).cuda()]
+    low = torch.randn(1, 48, 512, 512, generator=gen).cuda()
+    out = training.step_backward(g, x, c, low=low)
+    params = [p for p in g.parameters() if p.grad is not None]
+    assert len(params) == 80
+    vs = [torch.randn(p.shape, generator=gen).cuda() * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    slope = sum(float((p.grad.double() * v.double()).sum()) for p, v in zip(params, vs))
+    eps = 2e-2
+
+    def loss_at(sign):
+        with torch.no_grad():
+            for p, v in zip(params, vs):
+                p.add_(v, alpha=sign * eps)
+        try:
+            for p in params:
+                p.grad = None
+            return float(training.step_backward(g, x, c, low=low)["full_loss"])
+        finally:
+            with torch.no_grad():
+                for p, v in zip(params, vs):
+                    p.add_(v, alpha=-sign * eps)
+
+    fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
+    assert abs(fd - slope) <= 2e-2 * abs(slope) + 1e-7, (fd, slope, float(out["full_loss"]))
