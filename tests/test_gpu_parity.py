@@ -620,6 +620,34 @@ def test_bn_running_update_matches_torch_batchnorm():
     assert int(nbt) == int(ref.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("cfg", [(16, 64, 3, "configs[0]: 64x64x16, 2-scale"), (48, 256, 4, "configs[1]: 256x256x48, 3-scale")])
+def test_baseline_small_configs_inverse_vs_oracle(cfg):
+    """BASELINE.json configs[0] and configs[1]: the k-scale inverse on a synthetic lowest-resolution volume (no LRNN: its
+    mean branch is hard-wired to 512^2, networks.py:472,528), default-init weights, against the CPU oracle."""
+    from cwfa_amd import CWFA
+    from oracle import cwfa_oracle as O
+    D, side, S, what = cfg
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(D, side, S, with_lrnn=False, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    cond_input = torch.randn(1, 29, side, side, generator=g)
+    mean_cache = [0.1 * torch.randn(1, D // 2 ** (n + 1), side, side, generator=g) for n in range(S - 1)]
+    low = torch.randn(1, D // 2 ** (S - 1), side, side, generator=g)
+    with torch.no_grad():
+        vols = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache], low=low.cuda(), keep_all=True)
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    steps = []
+    for n, gi in enumerate(conv_inn):
+        axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+        steps.append({"inn": cpu(gi.state_dict()), "omega": cpu(cond_nets[n].state_dict()), "axes": axes})
+    with torch.no_grad():
+        ref = O.inverse_pass(steps, low, cond_input, mean_cache)
+    assert vols[-1].shape == (1, D, side, side)
+    for i, (a, b) in enumerate(zip(vols, ref)):
+        assert_close(a, b, TOL, f"{what}, level {i}")
+
+
 def test_full_config3_inverse_vs_oracle():
     """BASELINE.json configs[2] at FULL size -- 512x512x96, LRNN (train-mode BatchNorm as CWFA.py:532) + 4 flow steps with
     their condition nets, default-init weights -- against the CPU oracle on identical inputs.  The stochastic layers
