@@ -233,6 +233,11 @@ def main():
                 res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3), B)
             except Exception as exc:                          # noqa: BLE001
                 res["experiment_split_bf16"] = {"error": repr(exc)[:300]}
+        if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
+            try:                                              # BASELINE.json configs[4]: bf16 operands in the heavy convolutions
+                res["experiment_bf16"] = bf16_experiment(ops, step, max(a.steps // 2, 3), B)
+            except Exception as exc:                          # noqa: BLE001
+                res["experiment_bf16"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_lrnn and not a.no_experiment:
             try:
                 res["experiment_train_step"] = train_experiment(conv_inn, dev, a, max(a.steps // 4, 3))
@@ -268,6 +273,25 @@ def split_experiment(ops, step, steps, batch):
             "note": "opt-in, not the headline configuration: operands split exactly into three bf16 pieces, six partial "
                     "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; parity tests hold the fp32 path's bounds "
                     "(tests/test_gpu_parity.py::test_split_bf16_*)"}
+
+
+def bf16_experiment(ops, step, steps, batch):
+    """NOT the headline (which is fp32): BASELINE.json configs[4], the same step with plain bf16 operands in the heavy
+    convolutions (fp32 accumulation), measured after the timed region."""
+    ops.set_precision("bf16")
+    try:
+        step(); step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        ops.set_precision("fp32")
+    return {"value": batch / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "dtype": "bf16 operands, f32 accumulate",
+            "note": "configs[4]; parity (max-rel <= 1e-2, L2-rel <= 5e-3 vs the fp32 oracle) in "
+                    "tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle"}
 
 
 def train_experiment(conv_inn, dev, a, steps):

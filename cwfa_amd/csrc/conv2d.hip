@@ -81,6 +81,7 @@ struct ConvParams {
     // fused sub-network layer only
     const float* w1x1;      // [32 k-steps][2][64 lanes] panel of the 1x1 conv
     const float* b1x1;
+    int products;           // split-bf16 kernels: 6 = fp32-accurate (three pieces per operand), 1 = plain bf16 operands
 };
 
 struct Tile {
@@ -683,6 +684,10 @@ int launch(const ConvParams& p, int epi, hipStream_t st) {
     return launch_sel<C, ALLOWED, false>(p, epi, st);
 }
 
+}  // namespace
+int g_cwfa_split_products = 6;
+namespace {
+
 int fill_params(ConvParams& p, const char* name, const float* x, const float* w_packed, float* y, int B, int Cin, int H,
                 int W, int Cout, int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts) {
     CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "%s: bad size", name);
@@ -693,6 +698,7 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
     p.x = x; p.wp = w_packed; p.y = y;
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.x_bs = x_bs; p.y_bs = y_bs;
+    p.products = g_cwfa_split_products;
     if (opts) p.o = *opts;
     CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "%s: in_scale without in_shift", name);
     CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
@@ -805,6 +811,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     const Tile t = make_tile<C>(p);
+    const bool six = p.products != 1;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t HW = (int64_t)p.H * p.W;
     constexpr unsigned OOB = 0x80000000u;
@@ -874,11 +881,13 @@ __global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
             for (int m = 0; m < 2; ++m) {
                 // smallest terms first: (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
                 f32x16 c = acc[m][n];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][2], Bq[n & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][1], c, 0, 0, 0);
+                if (six) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][2], Bq[n & 1][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][1], Bq[n & 1][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][1], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][0], Bq[n & 1][0], c, 0, 0, 0);
                 acc[m][n] = c;
             }
@@ -913,6 +922,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);                   // [2 x CS3_XB input][3 x CS_WB weights][affine tables]
     const Tile t = make_tile<C>(p);
+    const bool six = p.products != 1;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t HW = (int64_t)p.H * p.W;
     constexpr unsigned OOB = 0x80000000u;
@@ -1116,11 +1126,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     f32x16 c = acc[m][n];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][2], Bq[n & 1][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][1], c, 0, 0, 0);
+                    if (six) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][2], Bq[n & 1][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][1], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][0], c, 0, 0, 0);
                     acc[m][n] = c;
                 }
@@ -1157,6 +1169,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);                   // [input tile SL_XB][3 x SL_WB weight slices]
     const Tile t = make_tile<C>(p);
+    const bool six = p.products != 1;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t HW = (int64_t)p.H * p.W;
     constexpr unsigned OOB = 0x80000000u;
@@ -1259,14 +1272,20 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
     __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                SL_MFMA(0, n, 2, 0); SL_MFMA(1, n, 2, 0); SL_MFMA(0, n, 1, 0); SL_MFMA(1, n, 1, 0);
+                if (six) {
+                    SL_MFMA(0, n, 2, 0); SL_MFMA(1, n, 2, 0); SL_MFMA(0, n, 1, 0); SL_MFMA(1, n, 1, 0);
+                }
                 SL_MFMA(0, n, 0, 0); SL_MFMA(1, n, 0, 0);
-                SL_MFMA(0, n, 1, 1); SL_MFMA(1, n, 1, 1); SL_MFMA(0, n, 0, 1); SL_MFMA(1, n, 0, 1);
+                if (six) {
+                    SL_MFMA(0, n, 1, 1); SL_MFMA(1, n, 1, 1); SL_MFMA(0, n, 0, 1); SL_MFMA(1, n, 0, 1);
+                }
                 if (n < 3) {                 // Bq[(n+1)&1] was last read by step-part n-1
                     rdB(n + 1, 0); rdB(n + 1, 1); rdB(n + 1, 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                SL_MFMA(0, n, 0, 2); SL_MFMA(1, n, 0, 2);
+                if (six) {
+                    SL_MFMA(0, n, 0, 2); SL_MFMA(1, n, 0, 2);
+                }
             }
 #undef SL_MFMA
             // weight slice step+1 (issued one step ago) has landed; this step's own loads (1 DMA, 8 input loads in the
@@ -1569,6 +1588,11 @@ extern "C" int cwfa_set_option(const char* name, int value) {
     }
     if (strcmp(name, "winograd_2d") == 0) {
         g_cwfa_wino_2d = value;
+        return CWFA_OK;
+    }
+    if (strcmp(name, "split_products") == 0) {      // 6: fp32-accurate split; 1: plain bf16 operands (BASELINE configs[4])
+        CWFA_REQUIRE(value == 1 || value == 6, CWFA_E_INVAL, "cwfa_set_option: split_products must be 1 or 6");
+        g_cwfa_split_products = value;
         return CWFA_OK;
     }
     cwfa_set_error("cwfa_set_option: unknown option '%s'", name);

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv2d_wgrad", "elu_bwd", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "set_precision", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -685,6 +685,16 @@ def set_option(name, value):
         _split_bf16 = int(value)
         return
     check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")
+
+
+def set_precision(mode):
+    """"fp32" (default) | "split_bf16" (fp32-accurate: three bf16 pieces per operand, six products) | "bf16" (BASELINE.json
+    configs[4]: the heavy convolutions -- 1x1 / transposed >= 128 outputs, 3x3 >= 192 outputs, the 64-channel fused layers --
+    take plain bf16 operands with fp32 accumulation; wavelets, couplings, permutations and the small convs stay fp32)."""
+    if mode not in ("fp32", "split_bf16", "bf16"):
+        raise ValueError(f"set_precision: unknown mode {mode!r}")
+    set_option("split_products", 1 if mode == "bf16" else 6)
+    set_option("split_bf16", 0 if mode == "fp32" else 2)
 
 
 def concat_channels(parts):

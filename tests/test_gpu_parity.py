@@ -676,6 +676,21 @@ def test_full_config3_inverse_vs_oracle():
         ref = O.inverse_pass(steps, None, cond_input, mean_cache, lrnn_sd=cpu(enc.state_dict()), lrnn_train=True)[-1]
     assert out.shape == (1, 96, 512, 512)
     assert_close(out, ref, TOL, "full-size config-3 inverse")
+    # BASELINE.json configs[4]: the same inverse with bf16 operands in the heavy convolutions (fp32 accumulation; wavelets,
+    # couplings, permutations in fp32).  Tolerance re-stated for bf16 as SURVEY.md 8(d) measured on the reference's own
+    # CPU autocast: max|d|/max|ref| <= 1e-2 and L2-relative <= 5e-3 against the fp32 oracle.
+    from cwfa_amd import ops
+    from conftest import rel_err
+    ops.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            out16 = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    m16, l16 = rel_err(out16, ref)
+    assert m16 <= 1e-2 and l16 <= 5e-3, f"bf16 config: max-rel {m16:.3e}, l2-rel {l16:.3e}"
+    assert max(rel_err(out16, out)) > 1e-6, "the bf16 mode must actually run bf16 kernels"
 
 
 def test_full_size_forward_nll_vs_oracle():
