@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
     ap.add_argument("--no-experiment", action="store_true", help="skip the extra split-bf16 measurement after the timed region")
+    ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[4] (NOT the headline configuration): bf16 operands in "
+                    "the heavy convolutions, fp32 accumulation; the line's dtype says so")
     ap.add_argument("--split-bf16", type=int, default=0, choices=(0, 1, 2),
                     help="(experiment, NOT the headline configuration) fp32-accurate split-bf16 matrix-core kernels: 1 = 1x1 / "
                          "transposed convolutions with >= 128 outputs, 2 = also the 3x3 convolutions with >= 192 outputs; the "
@@ -126,7 +128,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     from cwfa_amd import CWFA, ops
-    if a.split_bf16:
+    if a.bf16:
+        ops.set_precision("bf16")
+        a.split_bf16 = 2
+    elif a.split_bf16:
         ops.set_option("split_bf16", a.split_bf16)
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN
     torch.manual_seed(0)
@@ -186,7 +191,7 @@ def main():
             "metric": "volumes/sec inverse-pass @512x512x96 fp32", "value": world * a.steps * B / elapsed,
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not a.split_bf16 else f"f32 (split level {a.split_bf16}: 3-way split bf16 operands, six products, fp32 accumulate)",
+            "dtype": "bf16 (conv operands; f32 accumulate, f32 wavelets / couplings)" if a.bf16 else "f32" if not a.split_bf16 else f"f32 (split level {a.split_bf16}: 3-way split bf16 operands, six products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA (CAT x5 per scale, 64 ch) + "
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
