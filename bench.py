@@ -181,6 +181,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
+    nll_check = None
+    if world > 1:                                   # the metric's second half: "NLL match vs ref (1/2/4/8 GPU)"
+        try:
+            nll_check = sharded_nll_check(CWFA, conv_inn[0], a, dev, rank, world)
+        except Exception as exc:                    # noqa: BLE001  (after the timed region; must not cost the line)
+            nll_check = {"error": repr(exc)[:300]}
+
     res = None
     if rank == 0:
         t_dom, n_dom, f_dom, shapes = sink.totals()[dom]
@@ -232,6 +239,8 @@ def main():
                                       "flops_per_launch": f2 / n2, "avg_launch_ms": t2 / n2, "launches_timed": n2,
                                       "algorithmic_bytes_per_launch": sum(conv_bytes(k) * n for k, n in sh2.items()) / n2,
                                       "share_of_conv_time": tot[ranked[1]][0] / all_conv_ms}
+        if nll_check is not None:
+            res["nll_check"] = nll_check
         res["roofline_dwt"] = dwt_roofline(ops, a, dev)
         if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
             try:                                              # never let the side experiment cost the headline line
@@ -258,6 +267,27 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def sharded_nll_check(CWFA, g0, a, dev, rank, world):
+    """BASELINE.json configs[3] on the ranks of this run: `world` synthetic volumes (same seed everywhere), rank r takes
+    volume r, the forward / NLL step of the finest flow, ONE all-reduce of the float64[3] shard sums (RCCL over xGMI) --
+    against the same NLL computed by this rank alone over all volumes (no collective).  After the timed region."""
+    import torch.distributed as dist
+    gen = torch.Generator().manual_seed(3)
+    D, S = a.depths, a.side
+    x = torch.randn(world, D, S, S, generator=gen).to(dev)
+    c = [torch.randn(world, D // 2, S, S, generator=gen).to(dev), (0.1 * torch.randn(world, D // 2, S, S, generator=gen)).to(dev)]
+    with torch.no_grad():
+        nll, _, _ = CWFA.nll_step(g0, x[rank:rank + 1].contiguous(), [t[rank:rank + 1].contiguous() for t in c])
+        _, logdet, sumsq = CWFA.nll_terms(g0, x, c)
+    ref = (0.5 * float(sumsq[0]) - float(logdet.double().sum()) / world) / (world * x[0].numel())
+    vals = torch.tensor([float(nll)], dtype=torch.float64, device=dev)
+    lo, hi = vals.clone(), vals.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return {"nll_sharded": float(nll), "nll_single_process": ref, "rel_diff": abs(float(nll) - ref) / abs(ref),
+            "identical_on_all_ranks": bool(float(lo) == float(hi)), "volumes": world, "tolerance": 1e-6}
 
 
 def split_experiment(ops, step, steps, batch):
