@@ -79,6 +79,10 @@ SIGNATURES = {
     "cwfa_conv3d_wgrad_workspace_bytes": (i64, [i, i, i, i]),
     "cwfa_conv3d_wgrad_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, i, f, p]),
     "cwfa_prelu_bwd_f32": (i, [p, p, p, p, p, i, i64, i64, i64, i64, p]),
+    "cwfa_plane_affine_f32": (i, [p, p, p, i, p, p, i, i, i64, i64, i64, i64, p]),
+    "cwfa_bn_bwd_stats_f32": (i, [p, p, p, p, i, i, i64, i64, i64, p]),
+    "cwfa_bn_act_bwd_f32": (i, [p, p, p, i, p, p, p, p, p, i, i, i64, i64, i64, i64, p]),
+    "cwfa_maxpool2_bwd_f32": (i, [p, p, p, p, i, i, i, i, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),

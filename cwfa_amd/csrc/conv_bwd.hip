@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gv = g[b * g_bs + i], ov = o[b * o_bs + i];
         y[b * y_bs + i] = ov > 0.f ? gv : alpha * gv;
-        da += ov > 0.f ? 0.0 : (double)(gv * (ov / alpha));
+        da += ov > 0.f ? 0.0 : (double)gv * ((double)ov / (double)alpha);
     }
     if (dalpha) {
         const double tot = cwfa_block_sum(da, red);
@@ -603,5 +603,175 @@ extern "C" int cwfa_prelu_bwd_f32(const float* g, const float* o, const float* a
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048), B), dim3(256), 0, (hipStream_t)stream, g, o, alpha, y, dalpha,
                        n, g_bs, o_bs, y_bs);
     CWFA_LAUNCH_CHECK("cwfa_prelu_bwd_f32");
+    return CWFA_OK;
+}
+
+// =====================================================================================================================
+// Backward pieces of the UNet (unet.py:72-113,161-195; train-mode BatchNorm as the LRNN runs, CWFA.py:532):
+//   plane_affine  : u = x * scale[(b,)c] + shift[(b,)c] (+ add)      -- materialises a BatchNorm (x dropout mask) output
+//   bn_bwd_stats  : S1[c] = sum g*m, S2[c] = sum g*m*y over (B,H,W)   -- the two reductions of BatchNorm's backward
+//   bn_act_bwd    : g_pre = (A[(b,)c]*g + Bc[c] + Cc[c]*y) * PReLU'(y), dalpha += sum (...)*min(q,0)
+//                   (A, Bc, Cc folded by the host from S1, S2, the batch statistics and gamma; y = PReLU(q) is the conv output)
+//   maxpool2_bwd  : gradient of the 2x2 max-pool routed to the first maximum of each window, plus the skip gradient
+// =====================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void plane_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int aff_bs, const float* __restrict__ add,
+                                                           float* __restrict__ y, int C, int64_t HW, int64_t x_bs, int64_t add_bs,
+                                                           int64_t y_bs) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= HW) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float s = scale ? scale[b * aff_bs + c] : 1.f, t = shift ? shift[b * aff_bs + c] : 0.f;
+    const float4 v = *reinterpret_cast<const float4*>(x + b * x_bs + (int64_t)c * HW + i);
+    float4 o{v.x * s + t, v.y * s + t, v.z * s + t, v.w * s + t};
+    if (add) {
+        const float4 a = *reinterpret_cast<const float4*>(add + b * add_bs + (int64_t)c * HW + i);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    *reinterpret_cast<float4*>(y + b * y_bs + (int64_t)c * HW + i) = o;
+}
+
+// grid (splits, C, B)
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ mask_bc, double* __restrict__ st, int C, int64_t HW,
+                                                           int64_t g_bs, int64_t y_bs) {
+    __shared__ double red[16];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float m = mask_bc ? mask_bc[b * C + c] : 1.f;
+    const float* pg = g + b * g_bs + (int64_t)c * HW;
+    const float* py = y + b * y_bs + (int64_t)c * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = pg[i] * m;
+        s1 += gv;
+        s2 += (double)gv * py[i];
+    }
+    s1 = cwfa_block_sum(s1, red);
+    s2 = cwfa_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&st[2 * c], s1);
+        atomicAdd(&st[2 * c + 1], s2);
+    }
+}
+
+// grid (splits, C, B)
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                         const float* __restrict__ A, int a_bs, const float* __restrict__ Bc,
+                                                         const float* __restrict__ Cc, const float* __restrict__ alpha_p,
+                                                         float* __restrict__ out, double* __restrict__ dalpha, int C, int64_t HW,
+                                                         int64_t g_bs, int64_t y_bs, int64_t o_bs) {
+    __shared__ double red[16];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float a = A[b * a_bs + c], bc = Bc[c], cc = Cc[c];
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const float* pg = g + b * g_bs + (int64_t)c * HW;
+    const float* py = y + b * y_bs + (int64_t)c * HW;
+    float* po = out + b * o_bs + (int64_t)c * HW;
+    double da = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
+        const float yv = py[i];
+        const float gy = a * pg[i] + bc + cc * yv;
+        if (alpha_p) {
+            po[i] = yv > 0.f ? gy : alpha * gy;
+            da += yv > 0.f ? 0.0 : (double)gy * ((double)yv / (double)alpha);
+        } else {
+            po[i] = gy;
+        }
+    }
+    if (dalpha && alpha_p) {
+        const double tot = cwfa_block_sum(da, red);
+        if (threadIdx.x == 0) atomicAdd(dalpha, tot);
+    }
+}
+
+// thread = one 2x2 window; full [B*C][H][W] (H, W even), g_pool [B*C][H/2][W/2]
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ full, const float* __restrict__ g_pool,
+                                                           const float* __restrict__ g_skip, float* __restrict__ g_full, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t n = (int64_t)Ho * Wo;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t bc = blockIdx.y;
+    const int oy = (int)(i / Wo), ox = (int)(i % Wo);
+    const float* pf = full + bc * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+    const float v[4] = {pf[0], pf[1], pf[W], pf[W + 1]};
+    int arg = 0;
+    float m = v[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (v[k] > m || v[k] != v[k]) {      // first maximum in window order, NaN wins: ATen's max-pool index rule
+            m = v[k];
+            arg = k;
+        }
+    const float gp = g_pool[bc * n + i];
+    const int64_t base = bc * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+    const int64_t offs[4] = {0, 1, W, (int64_t)W + 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o = k == arg ? gp : 0.f;
+        if (g_skip) o += g_skip[base + offs[k]];
+        g_full[base + offs[k]] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int cwfa_plane_affine_f32(const float* x, const float* scale, const float* shift, int per_sample, const float* add, float* y,
+                                     int B, int C, int64_t HW, int64_t x_bs, int64_t add_bs, int64_t y_bs, void* stream) {
+    CWFA_REQUIRE(x && y, CWFA_E_INVAL, "cwfa_plane_affine_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && B <= 65535 && C <= 65535, CWFA_E_SHAPE, "cwfa_plane_affine_f32: bad shape");
+    CWFA_REQUIRE(HW % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && (!add || add_bs % 4 == 0), CWFA_E_SHAPE,
+                 "cwfa_plane_affine_f32: plane size and strides must be multiples of 4 elements");
+    CWFA_REQUIRE(cwfa_aligned16(x) && cwfa_aligned16(y) && (!add || cwfa_aligned16(add)), CWFA_E_ALIGN,
+                 "cwfa_plane_affine_f32: pointers must be 16-byte aligned");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    hipLaunchKernelGGL(plane_affine_kernel, dim3((unsigned)((HW / 4 + 255) / 256), C, B), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, per_sample ? C : 0, add, y, C, HW, x_bs, add_bs, y_bs);
+    CWFA_LAUNCH_CHECK("cwfa_plane_affine_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_bn_bwd_stats_f32(const float* g, const float* y, const float* mask_bc, double* stats, int B, int C, int64_t HW,
+                                     int64_t g_bs, int64_t y_bs, void* stream) {
+    CWFA_REQUIRE(g && y && stats, CWFA_E_INVAL, "cwfa_bn_bwd_stats_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && B <= 65535 && C <= 65535, CWFA_E_SHAPE, "cwfa_bn_bwd_stats_f32: bad shape");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    int64_t splits = (HW + 256 * 16 - 1) / (256 * 16);
+    const int64_t cap = 2048 / ((int64_t)B * C) + 1;
+    if (splits > cap) splits = cap;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)splits, C, B), dim3(256), 0, (hipStream_t)stream, g, y, mask_bc, stats, C, HW,
+                       g_bs, y_bs);
+    CWFA_LAUNCH_CHECK("cwfa_bn_bwd_stats_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_bn_act_bwd_f32(const float* g, const float* y, const float* A, int per_sample, const float* Bc, const float* Cc,
+                                   const float* alpha, float* out, double* dalpha, int B, int C, int64_t HW, int64_t g_bs,
+                                   int64_t y_bs, int64_t out_bs, void* stream) {
+    CWFA_REQUIRE(g && y && A && Bc && Cc && out, CWFA_E_INVAL, "cwfa_bn_act_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && B <= 65535 && C <= 65535, CWFA_E_SHAPE, "cwfa_bn_act_bwd_f32: bad shape");
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    int64_t splits = (HW + 256 * 16 - 1) / (256 * 16);
+    const int64_t cap = 2048 / ((int64_t)B * C) + 1;
+    if (splits > cap) splits = cap;
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)splits, C, B), dim3(256), 0, (hipStream_t)stream, g, y, A, per_sample ? C : 0, Bc,
+                       Cc, alpha, out, dalpha, C, HW, g_bs, y_bs, out_bs);
+    CWFA_LAUNCH_CHECK("cwfa_bn_act_bwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_maxpool2_bwd_f32(const float* full, const float* g_pool, const float* g_skip, float* g_full, int B, int C, int H,
+                                     int W, void* stream) {
+    CWFA_REQUIRE(full && g_pool && g_full, CWFA_E_INVAL, "cwfa_maxpool2_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, CWFA_E_SHAPE,
+                 "cwfa_maxpool2_bwd_f32: even H and W only (non-overlapping 2x2 windows)");
+    CWFA_REQUIRE((int64_t)B * C <= 65535, CWFA_E_SHAPE, "cwfa_maxpool2_bwd_f32: B*C too large");
+    if (B == 0 || C == 0) return CWFA_OK;
+    const int64_t n = (int64_t)(H / 2) * (W / 2);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256), B * C), dim3(256), 0, (hipStream_t)stream, full, g_pool,
+                       g_skip, g_full, H, W);
+    CWFA_LAUNCH_CHECK("cwfa_maxpool2_bwd_f32");
     return CWFA_OK;
 }

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv2d_wgrad", "elu_bwd", "set_precision", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "set_precision", "plane_affine", "bn_bwd_stats", "bn_act_bwd", "maxpool2_bwd", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -485,6 +485,69 @@ def elu_bwd(g, a, add=None, out=None):
     if o2.data_ptr() != out.data_ptr():
         raise ValueError("elu_bwd: `out` must have contiguous planes")
     check(L.cwfa_elu_bwd_f32(_p(g), _p(a), _p(add), _p(out), B, n, gbs, abs_, addbs, obs, _stream()), "elu_bwd")
+    return out
+
+
+def plane_affine(x, scale=None, shift=None, add=None):
+    """x * scale + shift (+ add) with [C] or [B,C] tables: a BatchNorm (x dropout mask) output as a tensor."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    B, Cc, H, W = x.shape
+    per = 0
+    if scale is not None:
+        scale, shift = _dev(scale).contiguous(), _dev(shift).contiguous()
+        if scale.numel() not in (Cc, B * Cc) or shift.numel() != scale.numel():
+            raise ValueError("plane_affine: scale / shift must be [C] or [B,C]")
+        per = int(scale.numel() == B * Cc and B > 1)
+    abs_ = 0
+    if add is not None:
+        add, abs_ = planes(add, "add")
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(L.cwfa_plane_affine_f32(_p(x), _p(scale), _p(shift), per, _p(add), _p(out), B, Cc, H * W, xbs, abs_, Cc * H * W, _stream()),
+          "plane_affine")
+    return out
+
+
+def bn_bwd_stats(g, y, mask_bc=None):
+    """float64 [C,2]: (sum g*m, sum g*m*y) over (B,H,W)."""
+    L = _lib.lib()
+    g, gbs = planes(g, "g")
+    y, ybs = planes(y, "y")
+    B, Cc, H, W = g.shape
+    st = torch.zeros(2 * Cc, dtype=torch.float64, device=g.device)
+    check(L.cwfa_bn_bwd_stats_f32(_p(g), _p(y), _p(None if mask_bc is None else _dev(mask_bc).contiguous()), _p(st), B, Cc, H * W, gbs,
+                                  ybs, _stream()), "bn_bwd_stats")
+    return st.view(Cc, 2)
+
+
+def bn_act_bwd(g, y, A, Bc, Cc_, alpha=None, dalpha=None, out=None):
+    """(A*g + Bc + Cc*y) * PReLU'(y) (alpha None: identity activation); A is [C] or [B,C]."""
+    L = _lib.lib()
+    g, gbs = planes(g, "g")
+    y, ybs = planes(y, "y")
+    B, Cc, H, W = g.shape
+    A = _dev(A).contiguous()
+    per = int(A.numel() == B * Cc and B > 1)
+    if out is None:
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
+    o2, obs = planes(out, "out")
+    if o2.data_ptr() != out.data_ptr():
+        raise ValueError("bn_act_bwd: `out` must have contiguous planes")
+    check(L.cwfa_bn_act_bwd_f32(_p(g), _p(y), _p(A), per, _p(_dev(Bc).contiguous()), _p(_dev(Cc_).contiguous()),
+                                _p(None if alpha is None else _dev(alpha)), _p(out), _p(dalpha), B, Cc, H * W, gbs, ybs, obs, _stream()),
+          "bn_act_bwd")
+    return out
+
+
+def maxpool2_bwd(full, g_pool, g_skip=None):
+    L = _lib.lib()
+    full = _dev(full, "full").contiguous()
+    g_pool = _dev(g_pool, "g_pool").contiguous()
+    B, Cc, H, W = full.shape
+    if g_skip is not None:
+        g_skip = _dev(g_skip, "g_skip").contiguous()
+    out = torch.empty_like(full)
+    check(L.cwfa_maxpool2_bwd_f32(_p(full), _p(g_pool), _p(g_skip), _p(out), B, Cc, H, W, _stream()), "maxpool2_bwd")
     return out
 
 

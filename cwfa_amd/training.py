@@ -27,7 +27,8 @@ import torch
 
 from . import ops
 
-__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "cond_forward_train", "cond_backward", "allreduce_gradients",
+__all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "cond_forward_train", "cond_backward", "unet_forward_train", "unet_backward",
+           "lrnn_forward_train", "lrnn_backward", "allreduce_gradients",
            "sgd_step"]
 
 
@@ -292,6 +293,168 @@ def cond_backward(tape, g_omega):
     ops.prelu_bwd(g_o1, tape.o1, a, dalpha, out=g_o1)               # o1 = PReLU(conv1(x))
     _conv_param_grads(c1, tape.x, g_o1)
     _acc(a, dalpha.to(torch.float32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UNet of the LRNN (unet.py:72-113,161-195), train-mode BatchNorm (CWFA.py:532)
+# ---------------------------------------------------------------------------------------------------------------------
+class _LayerRec:
+    __slots__ = ("conv", "alpha", "bn", "u", "y", "mean", "invstd", "mask", "n")
+
+
+def _prelu_of(act):
+    import torch.nn as nn
+    if not isinstance(act, nn.PReLU) or act.weight.numel() != 1:
+        raise NotImplementedError("UNet backward: single-parameter PReLU activations only (what the LRNN builds)")
+    return act.weight
+
+
+def _block_forward_train(block, u, out_mask):
+    """UNetConvBlock (conv3x3 -> PReLU -> BatchNorm) x 2, unfused: every BatchNorm output is materialised (the inference
+    path applies it inside the next convolution's load) because the weight gradient needs it as an operand."""
+    recs = []
+    layers = block._layers()
+    for li, (conv, act, bn) in enumerate(layers):
+        if bn is None:
+            raise NotImplementedError("UNet backward: blocks without BatchNorm")
+        alpha = _prelu_of(act)
+        y = ops.conv2d(u, block._packed.get(conv), bias=conv.bias, act="prelu", prelu_alpha=alpha)
+        m = out_mask if li == len(layers) - 1 else None
+        Cc = y.shape[1]
+        n = y.numel() // Cc
+        st = ops.channel_stats(y)
+        if bn.track_running_stats and bn.momentum is not None:
+            ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        sv = st.view(Cc, 2)
+        mean = sv[:, 0] / n
+        invstd = torch.rsqrt(sv[:, 1] / n - mean * mean + bn.eps)
+        scale = bn.weight.detach().double() * invstd
+        shift = bn.bias.detach().double() - mean * scale
+        if m is not None:
+            scale, shift = m.double() * scale[None, :], m.double() * shift[None, :]
+        r = _LayerRec()
+        r.conv, r.alpha, r.bn, r.u, r.y, r.mean, r.invstd, r.mask, r.n = conv, alpha, bn, u, y, mean, invstd, m, n
+        recs.append(r)
+        u = ops.plane_affine(y, scale.float(), shift.float())
+    return u, recs
+
+
+def _block_backward(recs, g):
+    """dL/d(block output) -> dL/d(block input); accumulates conv / BatchNorm / PReLU gradients."""
+    for r in reversed(recs):
+        st = ops.bn_bwd_stats(g, r.y, r.mask)
+        s1, s2 = st[:, 0], st[:, 1]
+        s2h = (s2 - r.mean * s1) * r.invstd                        # sum g m xhat
+        k = r.bn.weight.detach().double() * r.invstd
+        A = k if r.mask is None else r.mask.double() * k[None, :]
+        Cc = -k * r.invstd * s2h / r.n
+        Bc = -k * s1 / r.n - Cc * r.mean
+        _acc(r.bn.weight, s2h)
+        _acc(r.bn.bias, s1)
+        dalpha = torch.zeros(1, dtype=torch.float64, device=g.device)
+        g_pre = ops.bn_act_bwd(g, r.y, A.float(), Bc.float(), Cc.float(), r.alpha, dalpha)
+        _acc(r.alpha, dalpha)
+        _conv_param_grads(r.conv, r.u, g_pre)
+        g = ops.conv2d(g_pre, _packT(r.conv))
+    return g
+
+
+class _UNetTape:
+    __slots__ = ("unet", "down", "pools", "ups", "last_u", "out")
+
+
+def unet_forward_train(unet, x):
+    """``UNet.forward`` (unet.py:72-91) in training mode with everything the backward needs kept.  Returns (out, tape)."""
+    from .unet import _drop_mask
+    B, dev = x.shape[0], x.device
+    t = _UNetTape()
+    t.unet, t.down, t.pools, t.ups = unet, [], [], []
+    u, skips = x, []
+    for i, down in enumerate(unet.down_path):
+        u, recs = _block_forward_train(down, u, None)
+        t.down.append(recs)
+        if i != len(unet.down_path) - 1:
+            H, W = u.shape[2:]
+            if H % 2 or W % 2:
+                raise NotImplementedError("UNet backward: even feature-map sizes only")
+            full = u
+            pooled = ops.maxpool(full, H // 2, W // 2)
+            m = _drop_mask(unet.drop_out, B, pooled.shape[1], dev)
+            u = pooled if m is None else ops.plane_affine(pooled, m, torch.zeros_like(m))
+            t.pools.append((full, m))
+            skips.append(full)
+    for i, up in enumerate(unet.up_path):
+        m = _drop_mask(unet.drop_out, B, up.conv_block.block[0].out_channels, dev)
+        upv = ops.conv2d(u, up._packed.get(up.up, transposed=True), bias=up.up.bias)
+        v = ops.plane_affine(upv, add=up.center_crop(skips[-i - 1], upv.shape[2:])) if up.skip_conn else upv
+        u_in = u
+        u, recs = _block_forward_train(up.conv_block, v, m)
+        t.ups.append((up, u_in, recs))
+    alpha = _prelu_of(unet.last[1])
+    t.last_u = u
+    t.out = ops.conv2d(u, unet._packed.get(unet.last[0]), bias=unet.last[0].bias, act="prelu", prelu_alpha=alpha)
+    return t.out, t
+
+
+_packT4_cache = {}
+
+
+def _packT4(convT):
+    """1x1 filter bank of a ConvTranspose2d(k2,s2)'s data gradient: [Cin][Co*4] (cout index c*4 + dy*2 + dx, as the forward)."""
+    w = convT.weight
+    hit = _packT4_cache.get(id(convT))
+    if hit is None or hit[1] != w._version or hit[2] != w.data_ptr() or hit[0].epoch != ops.pack_epoch():
+        cin = w.shape[0]
+        hit = _packT4_cache[id(convT)] = (ops.pack_conv_weight(w.detach().reshape(cin, -1, 1, 1).contiguous()), w._version,
+                                          w.data_ptr())
+    return hit[0]
+
+
+def unet_backward(tape, g_out):
+    """Backward of ``unet_forward_train``: accumulates every parameter gradient, returns dL/d(input)."""
+    unet = tape.unet
+    alpha = _prelu_of(unet.last[1])
+    dalpha = torch.zeros(1, dtype=torch.float64, device=g_out.device)
+    g_pre = ops.prelu_bwd(g_out, tape.out, alpha, dalpha)
+    _acc(alpha, dalpha)
+    _conv_param_grads(unet.last[0], tape.last_u, g_pre)
+    g = ops.conv2d(g_pre, _packT(unet.last[0]))
+    n_skip = len(tape.pools)
+    g_skips = [None] * n_skip
+    for i in reversed(range(len(tape.ups))):
+        up, u_in, recs = tape.ups[i]
+        g_v = _block_backward(recs, g)                              # v = up(u_in) + skip
+        if up.skip_conn:
+            g_skips[n_skip - 1 - i] = g_v
+        B, Co, H2, W2 = g_v.shape
+        g4 = g_v.view(B, Co, H2 // 2, 2, W2 // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, Co * 4, H2 // 2, W2 // 2).contiguous()
+        w = up.up.weight
+        if up.up.bias is not None:
+            _acc(up.up.bias, ops.channel_stats(g_v).view(-1, 2)[:, 0])
+        dW4 = ops.conv2d_wgrad(u_in, g4, 1)                          # [4 Co, Cin, 1, 1]
+        _acc(w, dW4.view(Co, 2, 2, w.shape[0]).permute(3, 0, 1, 2))
+        g = ops.conv2d(g4, _packT4(up.up))
+    for i in reversed(range(len(tape.down))):
+        if i != len(tape.down) - 1:
+            full, m = tape.pools[i]
+            g_pool = g if m is None else ops.plane_affine(g, m, torch.zeros_like(m))
+            g = ops.maxpool2_bwd(full, g_pool, g_skips[i])
+        g = _block_backward(tape.down[i], g)
+    return g
+
+
+def lrnn_forward_train(lrnn, views):
+    """``LRNN.forward`` without the mean-volume branch (networks.py:544-551 with ``mean_vol=None``): 1x1 conv + UNet."""
+    c0 = lrnn.deconv[0]
+    x0 = ops.conv2d(views, lrnn._packed.get(c0), bias=c0.bias)
+    out, tape = unet_forward_train(lrnn.deconv[1], x0)
+    return out, (lrnn, views, tape)
+
+
+def lrnn_backward(tape, g_out):
+    lrnn, views, utape = tape
+    g_x0 = unet_backward(utape, g_out)
+    _conv_param_grads(lrnn.deconv[0], views, g_x0)
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):

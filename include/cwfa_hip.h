@@ -339,6 +339,23 @@ int cwfa_conv3d_wgrad_f32(const float* a, const float* src, const float* alpha, 
 int cwfa_prelu_bwd_f32(const float* g, const float* o, const float* alpha, float* y, double* dalpha, int B, int64_t n, int64_t g_bs,
                        int64_t o_bs, int64_t y_bs, void* stream);
 
+/* Backward pieces of the UNet (unet.py:72-113,161-195) with train-mode BatchNorm (CWFA.py:532):
+ *   plane_affine: y = x * scale[(b,)c] + shift[(b,)c] (+ add)  (per_sample != 0: [B,C] tables) -- the BatchNorm (x dropout mask)
+ *                 output as a tensor (the inference path applies it on load inside the next convolution);
+ *   bn_bwd_stats: stats[2c] += sum g*m, stats[2c+1] += sum g*m*y over (B,H,W), m = mask_bc[b][c] or 1 (double[2C], zeroed by caller);
+ *   bn_act_bwd:   out = (A[(b,)c]*g + Bc[c] + Cc[c]*y) * PReLU'(y) with y = PReLU(q) the conv output (alpha NULL: no activation),
+ *                 dalpha (nullable) += sum (...)*min(q,0) -- A, Bc, Cc folded by the caller from the statistics;
+ *   maxpool2_bwd: g_full = (first maximum of each 2x2 window of `full` ? g_pool : 0) + g_skip (nullable). */
+int cwfa_plane_affine_f32(const float* x, const float* scale, const float* shift, int per_sample, const float* add, float* y, int B,
+                          int C, int64_t HW, int64_t x_bs, int64_t add_bs, int64_t y_bs, void* stream);
+int cwfa_bn_bwd_stats_f32(const float* g, const float* y, const float* mask_bc, double* stats, int B, int C, int64_t HW, int64_t g_bs,
+                          int64_t y_bs, void* stream);
+int cwfa_bn_act_bwd_f32(const float* g, const float* y, const float* A, int per_sample, const float* Bc, const float* Cc,
+                        const float* alpha, float* out, double* dalpha, int B, int C, int64_t HW, int64_t g_bs, int64_t y_bs,
+                        int64_t out_bs, void* stream);
+int cwfa_maxpool2_bwd_f32(const float* full, const float* g_pool, const float* g_skip, float* g_full, int B, int C, int H, int W,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ Fixture index:
   g11_unet_*, g11_convnext, g11_attention, g11_lrnn_small, g11_lrnn_full
   g12_extract_views_*   XLFMDatasetFull.extract_views (needs only torch: imported from the reference file directly)
   g13_step_grad_*       autograd gradients of the training NLL of one CAT step (CWFA.py:966-978,1002-1006)
+  g14_unet_grad_*       autograd gradients of the UNet in train mode (unet.py:72-113,161-195)
 """
 import os
 import sys
@@ -443,8 +444,38 @@ def gen_step_grad():
              n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))
 
 
+def gen_unet_grad():
+    """g14: gradients of every UNet parameter (and of its input) in train mode -- batch-statistics BatchNorm, PReLU,
+    max-pool, skip additions, transposed convolutions (unet.py:72-113,161-195) -- from the reference's own modules and
+    torch autograd, for an arbitrary upstream gradient.  Dropout off (the reference's dropout draws from torch's RNG)."""
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    import torch
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(1414)
+    for bias in (False, True):
+        torch.manual_seed(41)
+        u = unet.UNet(5, 4, depth=3, wf=3, drop_out=0, use_bias=bias, skip_conn=True, up_mode="upconv", batch_norm=True)
+        with torch.no_grad():
+            for m_ in u.modules():
+                if isinstance(m_, torch.nn.BatchNorm2d):
+                    m_.weight.copy_(torch.rand(m_.weight.shape, generator=g) + 0.5)
+                    m_.bias.copy_(torch.randn(m_.bias.shape, generator=g) * 0.1)
+                if isinstance(m_, torch.nn.PReLU):
+                    m_.weight.copy_(0.1 + 0.3 * torch.rand(m_.weight.shape, generator=g))
+        sd0 = sd_arrays(u)
+        u.train()
+        x = torch.randn(3, 5, 16, 16, generator=g).requires_grad_()      # square: the reference pools to (W//2, W//2), unet.py:79
+        dy = torch.randn(3, 4, 16, 16, generator=g)
+        y = u(x)
+        (y * dy).sum().backward()
+        grads = {"grad/" + k: npy(p.grad) for k, p in u.named_parameters() if p.grad is not None}
+        dump(f"g14_unet_grad_bias{int(bias)}", x=npy(x), dy=npy(dy), y=npy(y), gx=npy(x.grad), **grads, **sd0)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extract_views":
+    if len(sys.argv) > 1 and sys.argv[1] == "unet_grad":
+        gen_unet_grad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extract_views":
         gen_extract_views()
     elif len(sys.argv) > 1 and sys.argv[1] == "step_grad":
         gen_step_grad()
@@ -452,3 +483,4 @@ if __name__ == "__main__":
         main()
         gen_extract_views()
         gen_step_grad()
+        gen_unet_grad()

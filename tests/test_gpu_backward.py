@@ -373,3 +373,29 @@ def test_full_size_directional_derivative():
 
     fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
     assert abs(fd - slope) <= 2e-2 * abs(slope) + 1e-7, (fd, slope, float(out["full_loss"]))
+
+
+@pytest.mark.parametrize("bias", [0, 1])
+def test_unet_backward_golden(bias):
+    """UNet in train mode (batch-statistics BatchNorm, PReLU, max-pool, skip adds, transposed convs; unet.py:72-113,161-195):
+    forward, input gradient and every parameter gradient against the reference's own autograd (fixture g14)."""
+    from conftest import load_golden, sd_of
+    from cwfa_amd import training
+    from cwfa_amd.unet import UNet
+    fx = load_golden(f"g14_unet_grad_bias{bias}")
+    u = UNet(5, 4, depth=3, wf=3, drop_out=0, use_bias=bool(bias), skip_conn=True, up_mode="upconv", batch_norm=True)
+    u.load_state_dict(sd_of(fx))
+    u = u.train().cuda()
+    out, tape = training.unet_forward_train(u, torch.from_numpy(fx["x"]).cuda())
+    assert_close(out, fx["y"], TOL, "train-mode forward")
+    gx = training.unet_backward(tape, torch.from_numpy(fx["dy"]).cuda())
+    assert_close(gx, fx["gx"], TOL, "input gradient")
+    want = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    got = {k: p.grad for k, p in u.named_parameters() if p.grad is not None}
+    assert set(got) == set(want), sorted(set(got) ^ set(want))[:6]
+    from conftest import rel_err
+    # a PReLU slope gradient is ONE number, a sum with heavy cancellation over every element of a feature map: the
+    # reference's own fp32 autograd carries ~1e-4 of relative noise there, so scalars get 1e-3
+    bad = [(k, max(rel_err(got[k], want[k]))) for k in sorted(want)
+           if not max(rel_err(got[k], want[k])) <= (1e-3 if want[k].size == 1 else TOL)]
+    assert not bad, bad[:8]
