@@ -79,3 +79,34 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def lrnn_time():
+    """LRNN without the mean-volume branch (1x1 conv + UNet 256/512/1024) at 512x512: train-mode forward + backward, B = 1."""
+    from cwfa_amd import networks as N
+    torch.manual_seed(0)
+    enc = N.Encoder(29, 6, 5, 64, True).cuda().train()
+    lr = enc.net
+    lr.deconv[1].drop_out = 0
+    gen = torch.Generator().manual_seed(5)
+    views = torch.randn(1, 29, 512, 512, generator=gen).cuda()
+    gt = torch.randn(1, 6, 512, 512, generator=gen).cuda()
+    params = [p for p in lr.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out, tape = training.lrnn_forward_train(lr, views)
+        g = ops.axpby(out, 2.0 / out.numel(), gt, -2.0 / out.numel())          # d mse / d out
+        training.lrnn_backward(tape, g)
+
+    with torch.no_grad():
+        fwd = ev_time(lambda: lr(views), reps=3, warm=1)
+    ms = ev_time(step, reps=3, warm=1)
+    n_par = sum(p.numel() for p in params if p.grad is not None)
+    print(f"LRNN (no mean branch) @512x512 B1: inference forward {fwd:.2f} ms, training step (forward with tape + backward, L2 loss) "
+          f"{ms:.2f} ms; {n_par/1e6:.1f} M parameters with gradients; peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "lrnn":
+    lrnn_time()
