@@ -36,24 +36,25 @@ struct WgParams {
     int64_t x_bs, dy_bs;
     int sx, sy;        // strips per row / per column of strips
     int nstrips;       // B * sy * sx
+    int row_off;       // added to the input row (the 7x7 gradient runs as seven 1x7 passes over row-shifted inputs)
 };
 
 constexpr int WG_CHP = 65;       // LDS words per pixel (64 channels + 1: conflict-free transposing stores)
 
-template <int KS>
+template <int KH, int KW>
 struct WgCfg {
-    static constexpr int TAPS = KS * KS, PADK = KS / 2;
-    static constexpr int XR = 2 + 2 * PADK, XC = 32 + 2 * PADK;
+    static constexpr int TAPS = KH * KW, PADH = KH / 2, PADW = KW / 2;
+    static constexpr int XR = 2 + 2 * PADH, XC = 32 + 2 * PADW;
     static constexpr int XW = XR * XC * WG_CHP, DW = 64 * WG_CHP;      // words of the x tile / the dy tile
     static constexpr int BUFW = XW + DW;
     static constexpr int LDS_BYTES = 2 * BUFW * 4;
     static constexpr int XLOADS = 64 * XR / 8;                        // core columns: (ci,row) pairs / 8 per pass
-    static constexpr int HLOADS = PADK ? 64 * XR * 2 / 256 : 0;         // halo columns
+    static constexpr int HLOADS = 64 * XR * 2 * PADW / 256;             // halo columns (2 * PADW of them)
 };
 
-template <int KS>
+template <int KH, int KW>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
-    typedef WgCfg<KS> C;
+    typedef WgCfg<KH, KW> C;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     const int mt = wave & 1, cit = wave >> 1;
@@ -79,17 +80,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
 #pragma unroll
             for (int j = 0; j < C::XLOADS; ++j) {
                 const int q = sq + 8 * j, ci = q / C::XR, r = q % C::XR;
-                const int gr = r0 + r - C::PADK;
+                const int gr = r0 + r - C::PADH + p.row_off;
                 const unsigned off = (gr >= 0 && gr < p.H && gc < p.W) ? (unsigned)ci * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
                 xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
             }
         }
-        if constexpr (C::HLOADS > 0) {      // x, the two halo columns: pair q = tid (ci = q / XR, row = q % XR), side j
-            const int ci = tid / C::XR, r = tid % C::XR;
-            const int gr = r0 + r - C::PADK;
+        if constexpr (C::HLOADS > 0) {      // x, the 2 * PADW halo columns: entry e = tid + 256 j -> (pair = (ci, row), halo column)
 #pragma unroll
             for (int j = 0; j < C::HLOADS; ++j) {
-                const int gc = c0 - 1 + 33 * j;
+                const int e = tid + 256 * j, hc = e % (2 * C::PADW), pair = e / (2 * C::PADW);
+                const int ci = pair / C::XR, r = pair % C::XR;
+                const int gr = r0 + r - C::PADH + p.row_off;
+                const int tc = hc < C::PADW ? hc : 32 + hc;                 // tile column
+                const int gc = c0 - C::PADW + tc;
                 const unsigned off = (gr >= 0 && gr < p.H && gc >= 0 && gc < p.W) ? (unsigned)ci * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
                 hr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
             }
@@ -111,12 +114,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
 #pragma unroll
         for (int j = 0; j < C::XLOADS; ++j) {
             const int q = sq + 8 * j, ci = q / C::XR, r = q % C::XR;
-            xs[(r * C::XC + scol + C::PADK) * WG_CHP + ci] = xr[j];
+            xs[(r * C::XC + scol + C::PADW) * WG_CHP + ci] = xr[j];
         }
         if constexpr (C::HLOADS > 0) {
-            const int ci = tid / C::XR, r = tid % C::XR;
 #pragma unroll
-            for (int j = 0; j < C::HLOADS; ++j) xs[(r * C::XC + 33 * j) * WG_CHP + ci] = hr[j];
+            for (int j = 0; j < C::HLOADS; ++j) {
+                const int e = tid + 256 * j, hc = e % (2 * C::PADW), pair = e / (2 * C::PADW);
+                const int ci = pair / C::XR, r = pair % C::XR;
+                xs[(r * C::XC + (hc < C::PADW ? hc : 32 + hc)) * WG_CHP + ci] = hr[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
             constexpr int row = s / 16, col = (2 * s) % 32;
             av[s & 1] = ds[(2 * s) * WG_CHP];
 #pragma unroll
-            for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = xs[((row + i / KS) * C::XC + col + i % KS) * WG_CHP];
+            for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = xs[((row + i / KW) * C::XC + col + i % KW) * WG_CHP];
         };
         fetch(std::integral_constant<int, 0>{});
         static_for<32>([&](auto sc) {
@@ -254,14 +260,29 @@ int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
 }  // namespace
 
 extern "C" int64_t cwfa_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int ks) {
-    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ks != 1 && ks != 3)) return 0;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (ks != 1 && ks != 3 && ks != 7)) return 0;
+    if (ks == 7)      // seven 1x7 passes: per-worker [Cout][Cin][7] partials + bias partials, and the reduced row
+        return ((int64_t)wgrad_workers(B, H, W, Cout, Cin, 3) * ((int64_t)Cout * Cin * 7 + Cout) + (int64_t)Cout * Cin * 7) * 4;
     return (int64_t)wgrad_workers(B, H, W, Cout, Cin, ks) * ((int64_t)Cout * Cin * ks * ks + Cout) * 4;
 }
+
+namespace {
+// dw[co][ci][ky][kx] (7x7) <- beta * dw + row[co][ci][kx]
+__global__ __launch_bounds__(256) void wgrad_scatter_row_kernel(const float* __restrict__ row, float* __restrict__ dw, int64_t ncc, int ky,
+                                                                float beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncc * 7) return;
+    const int64_t cc = i / 7;
+    const int kx = (int)(i % 7);
+    float* d = dw + (cc * 7 + ky) * 7 + kx;
+    *d = beta != 0.f ? beta * *d + row[i] : row[i];
+}
+}  // namespace
 
 extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* db, void* workspace, int B, int Cin, int H,
                                      int W, int Cout, int ks, int64_t x_bs, int64_t dy_bs, float beta, void* stream) {
     CWFA_REQUIRE(x && dy && dw && workspace, CWFA_E_INVAL, "cwfa_conv2d_wgrad_f32: null pointer");
-    CWFA_REQUIRE(ks == 1 || ks == 3, CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: kernel size %d (1 and 3 are built)", ks);
+    CWFA_REQUIRE(ks == 1 || ks == 3 || ks == 7, CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: kernel size %d (1, 3 and 7 are built)", ks);
     CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: bad shape");
     CWFA_REQUIRE((int64_t)64 * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: image too large for 32-bit offsets");
     const int64_t n = (int64_t)Cout * Cin * ks * ks;
@@ -285,26 +306,54 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     const int64_t strips = (int64_t)B * p.sy * p.sx;
     CWFA_REQUIRE(strips < (1ll << 31), CWFA_E_SHAPE, "cwfa_conv2d_wgrad_f32: too many strips");
     p.nstrips = (int)strips;
-    const int workers = wgrad_workers(B, H, W, Cout, Cin, ks);
+    const int workers = wgrad_workers(B, H, W, Cout, Cin, ks == 7 ? 3 : ks);
+    if (ks == 7) {
+        const int64_t nrow = (int64_t)Cout * Cin * 7;
+        float* row = p.part + (int64_t)workers * (nrow + Cout);
+        static bool attr7 = false;
+        if (!attr7) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1, 7>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<1, 7>::LDS_BYTES);
+            CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr7 = true;
+        }
+        dim3 grid7(workers, (Cout + 63) / 64, (Cin + 63) / 64);
+        for (int ky = 0; ky < 7; ++ky) {
+            p.row_off = ky - 3;
+            p.bpart = (db && ky == 0) ? p.part + (int64_t)workers * nrow : nullptr;
+            hipLaunchKernelGGL((conv_wgrad_kernel<1, 7>), grid7, dim3(256), (WgCfg<1, 7>::LDS_BYTES), st, p);
+            CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nrow + 63) / 64)), dim3(256), 0, st, p.part, row, nrow, workers, 0.f);
+            hipLaunchKernelGGL(wgrad_scatter_row_kernel, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, row, dw,
+                               (int64_t)Cout * Cin, ky, beta);
+            CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+            if (p.bpart) {
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p.bpart, db, (int64_t)Cout,
+                                   workers, beta);
+                CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+            }
+        }
+        return CWFA_OK;
+    }
     p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
     if (ks == 3) {
         if (!attr3) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<3>::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, 3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<3, 3>::LDS_BYTES);
             CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr3 = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), WgCfg<3>::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<3, 3>), grid, dim3(256), (WgCfg<3, 3>::LDS_BYTES), st, p);
     } else {
         if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<1>::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<1, 1>::LDS_BYTES);
             CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr1 = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), WgCfg<1>::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), (WgCfg<1, 1>::LDS_BYTES), st, p);
     }
     CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw, n, workers, beta);
