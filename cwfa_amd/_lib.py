@@ -83,6 +83,9 @@ SIGNATURES = {
     "cwfa_bn_bwd_stats_f32": (i, [p, p, p, p, i, i, i64, i64, i64, p]),
     "cwfa_bn_act_bwd_f32": (i, [p, p, p, i, p, p, p, p, p, i, i, i64, i64, i64, i64, p]),
     "cwfa_maxpool2_bwd_f32": (i, [p, p, p, p, i, i, i, i, p]),
+    "cwfa_gelu_f32": (i, [p, p, p, i64, i, p]),
+    "cwfa_layernorm_bwd_f32": (i, [p, p, p, p, p, p, p, p, p, i, i64, p]),
+    "cwfa_attention_bwd_f32": (i, [p, p, p, p, p, p, p, p, p, i, i, i64, p]),
     "cwfa_split_workspace_bytes": (i64, [i, i, i64]),
     "cwfa_split_input_f32": (i, [p, p, i, i, i64, i64, p, p, i64, p, i64, p]),
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),

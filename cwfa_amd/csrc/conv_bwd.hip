@@ -824,3 +824,170 @@ extern "C" int cwfa_maxpool2_bwd_f32(const float* full, const float* g_pool, con
     CWFA_LAUNCH_CHECK("cwfa_maxpool2_bwd_f32");
     return CWFA_OK;
 }
+
+// =====================================================================================================================
+// Backward pieces of the LRNN's mean-volume branch (ConvNeXt networks.py:468-503, GlobalAttention :244-262, combine :552-554)
+// =====================================================================================================================
+namespace {
+
+constexpr int CWFA_ATT_BWD_MAXC = 8;      // attention backward keeps C*C*4 + 2C running sums per thread (the LRNN has C = 6)
+
+__device__ __forceinline__ float gelu_grad(float v) {      // d/dv [0.5 v (1 + erf(v / sqrt 2))]
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+// mode 0: y = GELU(p) + res (nullable);   mode 1: y = g * GELU'(p)
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ p, const float* __restrict__ other, float* __restrict__ y,
+                                                   int64_t n, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = p[i];
+    if (mode == 0)
+        y[i] = cwfa_gelu(v) + (other ? other[i] : 0.f);
+    else
+        y[i] = other[i] * gelu_grad(v);
+}
+
+// LayerNorm over (C,H,W) per sample, y = xhat * w + b:  st[2b] += sum g w, st[2b+1] += sum g w xhat      grid (splits, B)
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                           const float* __restrict__ w, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, double* __restrict__ st, int64_t n) {
+    __shared__ double red[16];
+    const int b = blockIdx.y;
+    const float mu = mean[b], is = invstd[b];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gw = g[b * n + i] * w[i];
+        s1 += gw;
+        s2 += (double)gw * ((v[b * n + i] - mu) * is);
+    }
+    s1 = cwfa_block_sum(s1, red);
+    s2 = cwfa_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&st[2 * b], s1);
+        atomicAdd(&st[2 * b + 1], s2);
+    }
+}
+
+// gv[b][i] = invstd_b * (g w - S1_b/n - xhat * S2_b/n);   dw[i] += sum_b g xhat;   db[i] += sum_b g
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                           const float* __restrict__ w, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const double* __restrict__ st,
+                                                           float* __restrict__ gv, float* __restrict__ dw, float* __restrict__ db, int B,
+                                                           int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float wi = w[i];
+    float aw = 0.f, ab = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float is = invstd[b];
+        const float xh = (v[b * n + i] - mean[b]) * is;
+        const float gi = g[b * n + i];
+        aw += gi * xh;
+        ab += gi;
+        gv[b * n + i] = is * (gi * wi - (float)(st[2 * b] / (double)n) - xh * (float)(st[2 * b + 1] / (double)n));
+    }
+    dw[i] += aw;
+    db[i] += ab;
+}
+
+// out = x + 2 m (att - 0.5), att = sigmoid(W2 relu(W1 *3 mean + b1) + b2) along the flattened H*W sequence.  Given g = dL/dout:
+// gm = 2 g (att - 0.5); parameter gradients of the attention (pgrad: [w1 C*C*3 | b1 C | w2 C*C | b2 C], doubles, accumulated).
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, const float* __restrict__ m,
+                                                            const float* __restrict__ g, float* __restrict__ gm,
+                                                            double* __restrict__ pgrad, int C, int64_t L) {
+    __shared__ double red[16];
+    const int b = blockIdx.y;
+    const float* pm = mean + (int64_t)b * C * L;
+    constexpr int MC = CWFA_ATT_BWD_MAXC;
+    float aw1[MC * MC * 3], ab1[MC], aw2[MC * MC], ab2[MC];
+    for (int k = 0; k < C * C * 3; ++k) aw1[k] = 0.f;
+    for (int k = 0; k < C * C; ++k) aw2[k] = 0.f;
+    for (int k = 0; k < C; ++k) ab1[k] = ab2[k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+        float nb[MC][3], hid[MC], ga[MC], gh[MC];
+        for (int c = 0; c < C; ++c) {
+            nb[c][0] = i > 0 ? pm[(int64_t)c * L + i - 1] : 0.f;
+            nb[c][1] = pm[(int64_t)c * L + i];
+            nb[c][2] = i + 1 < L ? pm[(int64_t)c * L + i + 1] : 0.f;
+        }
+        for (int o = 0; o < C; ++o) {
+            float h = b1[o];
+            for (int c = 0; c < C; ++c) {
+                const float* ww = w1 + ((int64_t)o * C + c) * 3;
+                h = fmaf(ww[2], nb[c][2], fmaf(ww[1], nb[c][1], fmaf(ww[0], nb[c][0], h)));
+            }
+            hid[o] = h > 0.f ? h : 0.f;
+        }
+        for (int o = 0; o < C; ++o) {
+            float a = b2[o];
+            for (int c = 0; c < C; ++c) a = fmaf(w2[o * C + c], hid[c], a);
+            const float att = 1.f / (1.f + expf(-a));
+            const int64_t idx = ((int64_t)b * C + o) * L + i;
+            const float gv = g[idx], mv = m[idx];
+            gm[idx] = 2.f * gv * (att - 0.5f);
+            ga[o] = 2.f * gv * mv * att * (1.f - att);
+            ab2[o] += ga[o];
+            for (int c = 0; c < C; ++c) aw2[o * C + c] += ga[o] * hid[c];
+        }
+        for (int c = 0; c < C; ++c) {
+            float t = 0.f;
+            for (int o = 0; o < C; ++o) t = fmaf(w2[o * C + c], ga[o], t);
+            gh[c] = hid[c] > 0.f ? t : 0.f;
+            ab1[c] += gh[c];
+        }
+        for (int o = 0; o < C; ++o)
+            for (int c = 0; c < C; ++c)
+                for (int k = 0; k < 3; ++k) aw1[(o * C + c) * 3 + k] += gh[o] * nb[c][k];
+    }
+    const int n1 = C * C * 3, n2 = C * C;
+    for (int k = 0; k < n1 + C + n2 + C; ++k) {
+        const float val = k < n1 ? aw1[k] : k < n1 + C ? ab1[k - n1] : k < n1 + C + n2 ? aw2[k - n1 - C] : ab2[k - n1 - C - n2];
+        const double tot = cwfa_block_sum((double)val, red);
+        if (threadIdx.x == 0) atomicAdd(&pgrad[k], tot);
+    }
+}
+
+}  // namespace
+
+extern "C" int cwfa_gelu_f32(const float* p, const float* other, float* y, int64_t n, int mode, void* stream) {
+    CWFA_REQUIRE(p && y && (mode == 0 || other), CWFA_E_INVAL, "cwfa_gelu_f32: null pointer");
+    CWFA_REQUIRE(n >= 0 && (mode == 0 || mode == 1), CWFA_E_INVAL, "cwfa_gelu_f32: bad argument");
+    if (n == 0) return CWFA_OK;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, other, y, n, mode);
+    CWFA_LAUNCH_CHECK("cwfa_gelu_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_layernorm_bwd_f32(const float* g, const float* v, const float* w, const float* mean, const float* invstd,
+                                      double* stats, float* gv, float* dw, float* db, int B, int64_t n, void* stream) {
+    CWFA_REQUIRE(g && v && w && mean && invstd && stats && gv && dw && db, CWFA_E_INVAL, "cwfa_layernorm_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && n >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_layernorm_bwd_f32: bad shape");
+    if (B == 0 || n == 0) return CWFA_OK;
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, g, v, w, mean, invstd, stats, n);
+    CWFA_LAUNCH_CHECK("cwfa_layernorm_bwd_f32");
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, v, w, mean, invstd,
+                       stats, gv, dw, db, B, n);
+    CWFA_LAUNCH_CHECK("cwfa_layernorm_bwd_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_attention_bwd_f32(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      const float* m, const float* g, float* gm, double* pgrad, int B, int C, int64_t HW, void* stream) {
+    CWFA_REQUIRE(mean && w1 && b1 && w2 && b2 && m && g && gm && pgrad, CWFA_E_INVAL, "cwfa_attention_bwd_f32: null pointer");
+    CWFA_REQUIRE(C > 0 && C <= CWFA_ATT_BWD_MAXC, CWFA_E_SHAPE, "cwfa_attention_bwd_f32: C=%d not in 1..%d", C, CWFA_ATT_BWD_MAXC);
+    CWFA_REQUIRE(B >= 0 && HW >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_attention_bwd_f32: bad shape");
+    if (B == 0 || HW == 0) return CWFA_OK;
+    int blocks = (int)((HW + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, mean, w1, b1, w2, b2, m, g, gm, pgrad, C,
+                       HW);
+    CWFA_LAUNCH_CHECK("cwfa_attention_bwd_f32");
+    return CWFA_OK;
+}

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import AffineStage, Chain, ConvOpts, check
 
 __all__ = ["haar1d", "haar2d", "gather", "affine", "channel_affine", "chain_inv", "chain_fwd", "pack_conv_weight",
-           "conv2d", "conv2d_wgrad", "elu_bwd", "set_precision", "plane_affine", "bn_bwd_stats", "bn_act_bwd", "maxpool2_bwd", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
+           "conv2d", "conv2d_wgrad", "elu_bwd", "set_precision", "gelu_add", "gelu_bwd", "layernorm_bwd", "attention_bwd", "plane_affine", "bn_bwd_stats", "bn_act_bwd", "maxpool2_bwd", "chain_bwd", "chain_inv_bwd", "prelu_bwd", "conv3d_1k1_backward", "pack_1x1_panel", "pack_split_layer_weight", "subnet_layer", "conv3d_1k1", "channel_stats", "bn_fold", "bn_running_update", "maxpool", "sample_stats", "layernorm_apply",
            "attention_combine", "scale_channels", "axpby", "stage"]
 
 
@@ -549,6 +549,49 @@ def maxpool2_bwd(full, g_pool, g_skip=None):
     out = torch.empty_like(full)
     check(L.cwfa_maxpool2_bwd_f32(_p(full), _p(g_pool), _p(g_skip), _p(out), B, Cc, H, W, _stream()), "maxpool2_bwd")
     return out
+
+
+def gelu_add(p, res=None):
+    """GELU(p) + res (the unfused form of the ConvNeXt tail, kept for training: the backward needs p)."""
+    L = _lib.lib()
+    p = _dev(p, "p").contiguous()
+    res = None if res is None else _dev(res).contiguous()
+    out = torch.empty_like(p)
+    check(L.cwfa_gelu_f32(_p(p), _p(res), _p(out), p.numel(), 0, _stream()), "gelu")
+    return out
+
+
+def gelu_bwd(g, p):
+    L = _lib.lib()
+    p, g = _dev(p, "p").contiguous(), _dev(g, "g").contiguous()
+    out = torch.empty_like(p)
+    check(L.cwfa_gelu_f32(_p(p), _p(g), _p(out), p.numel(), 1, _stream()), "gelu_bwd")
+    return out
+
+
+def layernorm_bwd(g, v, weight, mean, invstd, dw, db):
+    """dL/dv of a LayerNorm over (C,H,W); ``dw`` / ``db`` (shape of the affine) are accumulated in place."""
+    L = _lib.lib()
+    g, v = _dev(g, "g").contiguous(), _dev(v, "v").contiguous()
+    B, n = v.shape[0], v[0].numel()
+    st = torch.zeros(2 * B, dtype=torch.float64, device=v.device)
+    gv = torch.empty_like(v)
+    check(L.cwfa_layernorm_bwd_f32(_p(g), _p(v), _p(_dev(weight).contiguous()), _p(_dev(mean).contiguous()), _p(_dev(invstd).contiguous()),
+                                   _p(st), _p(gv), _p(dw), _p(db), B, n, _stream()), "layernorm_bwd")
+    return gv
+
+
+def attention_bwd(mean, w1, b1, w2, b2, m, g):
+    """Backward of ``attention_combine(mean, ..., m, x)`` given g = dL/dout: (dL/dm, float64 [w1|b1|w2|b2] gradients); dL/dx = g."""
+    L = _lib.lib()
+    mean, m, g = _dev(mean).contiguous(), _dev(m).contiguous(), _dev(g).contiguous()
+    B, Cc = mean.shape[:2]
+    HW = mean[0, 0].numel()
+    gm = torch.empty_like(m)
+    pg = torch.zeros(Cc * Cc * 3 + Cc + Cc * Cc + Cc, dtype=torch.float64, device=mean.device)
+    check(L.cwfa_attention_bwd_f32(_p(mean), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(w2).contiguous()), _p(_dev(b2)), _p(m),
+                                   _p(g), _p(gm), _p(pg), B, Cc, HW, _stream()), "attention_bwd")
+    return gm, pg
 
 
 def prelu_bwd(g, o, alpha, dalpha=None, out=None):

@@ -443,17 +443,78 @@ def unet_backward(tape, g_out):
     return g
 
 
-def lrnn_forward_train(lrnn, views):
-    """``LRNN.forward`` without the mean-volume branch (networks.py:544-551 with ``mean_vol=None``): 1x1 conv + UNet."""
+def _convnext_forward_train(cn, x):
+    """ConvNeXt (networks.py:468-503): u = 1x1(x); out = GELU(1x1(LayerNorm_{C,H,W}(7x7(u)))) + drop_path(u), unfused."""
+    from .networks import drop_path
+    P = cn._packed.get
+    u = ops.conv2d(x, P(cn.input), bias=cn.input.bias)
+    v = ops.conv2d(u, P(cn.m[0]), bias=cn.m[0].bias)
+    ln = cn.m[1]
+    B, n = v.shape[0], v[0].numel()
+    st = ops.sample_stats(v).view(B, 2)
+    mean = st[:, 0] / n
+    invstd = torch.rsqrt(st[:, 1] / n - mean * mean + ln.eps)
+    vln = ops.layernorm_apply(v, st.reshape(-1), ln.weight, ln.bias, ln.eps)
+    p = ops.conv2d(vln, P(cn.m[2]), bias=cn.m[2].bias)
+    gate = None
+    if cn.drop_prob and cn.training:                      # per-sample stochastic depth on the residual (networks.py:370-385)
+        keep = 1 - cn.drop_prob
+        gate = torch.floor(keep + torch.rand(B, 1, dtype=u.dtype, device=u.device)) / keep
+        res = ops.scale_channels(u, gate.expand(B, u.shape[1]).contiguous())
+    else:
+        res = u
+    out = ops.gelu_add(p, res)
+    return out, (cn, x, u, v, vln, p, mean.float(), invstd.float(), gate)
+
+
+def _convnext_backward(tape, g_out, want_input_grad):
+    cn, x, u, v, vln, p, mean, invstd, gate = tape
+    ln = cn.m[1]
+    g_p = ops.gelu_bwd(g_out, p)
+    _conv_param_grads(cn.m[2], vln, g_p)
+    g_vln = ops.conv2d(g_p, _packT(cn.m[2]))
+    for t in (ln.weight, ln.bias):
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
+    g_v = ops.layernorm_bwd(g_vln, v, ln.weight, mean, invstd, ln.weight.grad, ln.bias.grad)
+    _conv_param_grads(cn.m[0], u, g_v)
+    g_u = ops.conv2d(g_v, _packT(cn.m[0]))
+    g_res = g_out if gate is None else ops.scale_channels(g_out, gate.expand(g_out.shape[0], g_out.shape[1]).contiguous())
+    g_u = ops.axpby(g_u, 1.0, g_res, 1.0)
+    _conv_param_grads(cn.input, x, g_u)
+    return ops.conv2d(g_u, _packT(cn.input)) if want_input_grad else None
+
+
+def lrnn_forward_train(lrnn, views, mean_vol=None):
+    """``LRNN.forward`` (networks.py:544-555) in training mode with a tape: 1x1 conv + UNet on the views, and with
+    ``mean_vol`` the mean-volume branch (two ConvNeXt blocks + global attention, combined as x + 2 m (att - 0.5))."""
     c0 = lrnn.deconv[0]
     x0 = ops.conv2d(views, lrnn._packed.get(c0), bias=c0.bias)
-    out, tape = unet_forward_train(lrnn.deconv[1], x0)
-    return out, (lrnn, views, tape)
+    x, utape = unet_forward_train(lrnn.deconv[1], x0)
+    if mean_vol is None:
+        return x, (lrnn, views, utape, None)
+    m1, t1 = _convnext_forward_train(lrnn.conv3d[0], mean_vol)
+    m, t2 = _convnext_forward_train(lrnn.conv3d[1], m1)
+    out = lrnn.attention_3d.combine(mean_vol, m, x)
+    return out, (lrnn, views, utape, (mean_vol, m, t1, t2))
 
 
 def lrnn_backward(tape, g_out):
-    lrnn, views, utape = tape
-    g_x0 = unet_backward(utape, g_out)
+    """Backward of ``lrnn_forward_train``: accumulates the .grad of every LRNN parameter the loss reaches."""
+    lrnn, views, utape, mtape = tape
+    if mtape is not None:
+        mean_vol, m, t1, t2 = mtape
+        att = lrnn.attention_3d.m
+        g_m, pg = ops.attention_bwd(mean_vol, att[0].weight, att[0].bias, att[2].weight, att[2].bias, m, g_out)
+        Cc = mean_vol.shape[1]
+        n1, n2 = Cc * Cc * 3, Cc * Cc
+        _acc(att[0].weight, pg[:n1])
+        _acc(att[0].bias, pg[n1:n1 + Cc])
+        _acc(att[2].weight, pg[n1 + Cc:n1 + Cc + n2])
+        _acc(att[2].bias, pg[n1 + Cc + n2:])
+        g_m1 = _convnext_backward(t2, g_m, True)
+        _convnext_backward(t1, g_m1, False)
+    g_x0 = unet_backward(utape, g_out)                              # dL/dx = g (out = x + ...)
     _conv_param_grads(lrnn.deconv[0], views, g_x0)
 
 

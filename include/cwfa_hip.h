@@ -356,6 +356,18 @@ int cwfa_bn_act_bwd_f32(const float* g, const float* y, const float* A, int per_
 int cwfa_maxpool2_bwd_f32(const float* full, const float* g_pool, const float* g_skip, float* g_full, int B, int C, int H, int W,
                           void* stream);
 
+/* Backward pieces of the LRNN's mean-volume branch (ConvNeXt networks.py:468-503, GlobalAttention :244-262, combine :552-554):
+ *   gelu:          mode 0: y = GELU(p) + other (nullable);  mode 1: y = other * GELU'(p)                       (n elements)
+ *   layernorm_bwd: LayerNorm over the n = C*H*W elements of each sample, y = xhat*w + b with xhat = (v - mean[b])*invstd[b]:
+ *                  gv = dL/dv, dw += sum_b g*xhat, db += sum_b g (dw, db ACCUMULATED); stats: double[2B] scratch, zeroed by the caller;
+ *   attention_bwd: out = x + 2 m (att - 0.5), att = sigmoid(W2 relu(W1 *3 mean + b1) + b2) over the flattened H*W sequence
+ *                  (C <= 8): gm = dL/dm, pgrad (double[C*C*3 + C + C*C + C], accumulated) = dL/d[w1 | b1 | w2 | b2]; dL/dx = g. */
+int cwfa_gelu_f32(const float* p, const float* other, float* y, int64_t n, int mode, void* stream);
+int cwfa_layernorm_bwd_f32(const float* g, const float* v, const float* w, const float* mean, const float* invstd, double* stats,
+                           float* gv, float* dw, float* db, int B, int64_t n, void* stream);
+int cwfa_attention_bwd_f32(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, const float* m,
+                           const float* g, float* gm, double* pgrad, int B, int C, int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

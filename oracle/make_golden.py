@@ -25,6 +25,7 @@ Fixture index:
   g12_extract_views_*   XLFMDatasetFull.extract_views (needs only torch: imported from the reference file directly)
   g13_step_grad_*       autograd gradients of the training NLL of one CAT step (CWFA.py:966-978,1002-1006)
   g14_unet_grad_*       autograd gradients of the UNet in train mode (unet.py:72-113,161-195)
+  g15_meanbranch_grad   autograd gradients of the LRNN's mean-volume branch (networks.py:468-503,244-262,552-554)
 """
 import os
 import sys
@@ -472,8 +473,40 @@ def gen_unet_grad():
         dump(f"g14_unet_grad_bias{int(bias)}", x=npy(x), dy=npy(dy), y=npy(y), gx=npy(x.grad), **grads, **sd0)
 
 
+def gen_meanbranch_grad():
+    """g15: gradients through the LRNN's mean-volume branch at a small size -- m = ConvNeXt(ConvNeXt(mean)),
+    att = GlobalAttention(mean), out = x + m*2*(att - 0.5) (networks.py:468-503,244-262,552-554) -- from the reference's
+    modules and torch autograd.  drop_path off (it draws from torch's RNG)."""
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    import torch
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(1515)
+    torch.manual_seed(51)
+    cn1 = networks.ConvNeXt(6, 10, drop_prob=0.0, size=16).train()
+    cn2 = networks.ConvNeXt(10, 6, drop_prob=0.0, size=16).train()
+    ga = networks.GlobalAttention(6).train()
+    with torch.no_grad():
+        for cn in (cn1, cn2):
+            cn.m[1].weight.copy_(1 + 0.2 * torch.randn(cn.m[1].weight.shape, generator=g))
+            cn.m[1].bias.copy_(0.1 * torch.randn(cn.m[1].bias.shape, generator=g))
+    mean = torch.randn(2, 6, 16, 16, generator=g)
+    x = torch.randn(2, 6, 16, 16, generator=g).requires_grad_()
+    dy = torch.randn(2, 6, 16, 16, generator=g)
+    m = cn2(cn1(mean))
+    att = ga(mean.view(2, 6, -1)).view(2, 6, 16, 16)
+    out = x + m * 2 * (att - 0.5)
+    (out * dy).sum().backward()
+    arrs = {"mean": npy(mean), "x": npy(x), "dy": npy(dy), "out": npy(out), "m": npy(m), "gx": npy(x.grad)}
+    for tag, mod in (("cn1", cn1), ("cn2", cn2), ("ga", ga)):
+        arrs.update(sd_arrays(mod, f"sd_{tag}/"))
+        arrs.update({f"grad_{tag}/" + k: npy(p.grad) for k, p in mod.named_parameters() if p.grad is not None})
+    dump("g15_meanbranch_grad", **arrs)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "unet_grad":
+    if len(sys.argv) > 1 and sys.argv[1] == "meanbranch_grad":
+        gen_meanbranch_grad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "unet_grad":
         gen_unet_grad()
     elif len(sys.argv) > 1 and sys.argv[1] == "extract_views":
         gen_extract_views()
@@ -484,3 +517,4 @@ if __name__ == "__main__":
         gen_extract_views()
         gen_step_grad()
         gen_unet_grad()
+        gen_meanbranch_grad()

@@ -400,3 +400,44 @@ def test_unet_backward_golden(bias):
     bad = [(k, max(rel_err(got[k], want[k]))) for k in sorted(want)
            if not max(rel_err(got[k], want[k])) <= (1e-3 if want[k].size == 1 else TOL)]
     assert not bad, bad[:8]
+
+
+def test_lrnn_mean_branch_backward_golden():
+    """The LRNN's mean-volume branch at a small size (two ConvNeXt blocks: 1x1, 7x7, LayerNorm over (C,H,W), 1x1 + GELU,
+    residual; GlobalAttention; out = x + 2 m (att - 0.5); networks.py:468-503,244-262,552-554): forward and every gradient
+    against the reference's own autograd (fixture g15)."""
+    from conftest import load_golden, rel_err, sd_of
+    from cwfa_amd import networks as N, ops, training
+    fx = load_golden("g15_meanbranch_grad")
+    cn1, cn2, ga = N.ConvNeXt(6, 10, drop_prob=0.0, size=16), N.ConvNeXt(10, 6, drop_prob=0.0, size=16), N.GlobalAttention(6)
+    for tag, mod in (("cn1", cn1), ("cn2", cn2), ("ga", ga)):
+        mod.load_state_dict(sd_of(fx, f"sd_{tag}/"))
+        mod.train().cuda()
+    cu = lambda k: torch.from_numpy(fx[k]).cuda()       # noqa: E731
+    mean, x, dy = cu("mean"), cu("x"), cu("dy")
+    m1, t1 = training._convnext_forward_train(cn1, mean)
+    m, t2 = training._convnext_forward_train(cn2, m1)
+    assert_close(m, fx["m"], TOL, "m = ConvNeXt(ConvNeXt(mean))")
+    out = ga.combine(mean, m, x)
+    assert_close(out, fx["out"], TOL, "combined output")
+    att = ga.m
+    g_m, pg = ops.attention_bwd(mean, att[0].weight, att[0].bias, att[2].weight, att[2].bias, m, dy)
+    g_m1 = training._convnext_backward(t2, g_m, True)
+    training._convnext_backward(t1, g_m1, False)
+    bad = []
+    n1, n2 = 6 * 6 * 3, 6 * 6
+    got_ga = {"m.0.weight": pg[:n1].reshape(6, 6, 3), "m.0.bias": pg[n1:n1 + 6], "m.2.weight": pg[n1 + 6:n1 + 6 + n2].reshape(6, 6, 1),
+              "m.2.bias": pg[n1 + 6 + n2:]}
+    for k, v in got_ga.items():
+        e = max(rel_err(v, fx["grad_ga/" + k]))
+        if not e <= TOL:
+            bad.append(("ga." + k, e))
+    for tag, mod in (("cn1", cn1), ("cn2", cn2)):
+        want = {k[len(f"grad_{tag}/"):]: v for k, v in fx.items() if k.startswith(f"grad_{tag}/")}
+        got = {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+        assert set(got) == set(want), (tag, sorted(set(got) ^ set(want)))
+        for k in sorted(want):
+            e = max(rel_err(got[k], want[k]))
+            if not e <= TOL:
+                bad.append((tag + "." + k, e))
+    assert not bad, bad
