@@ -17,9 +17,9 @@ rank scales its local gradient by the global 1/numel and the ranks' gradients ar
 packs them into a few large flat buckets (default 64 MiB: the flow parameters of one step are 13.7 MB, so one message)
 and issues one all-reduce per bucket (RCCL over xGMI on MI355X; gloo in the CPU test).
 
-Scope: gradients of a flow step's own parameters (the reference's ``optimizer``) and of its condition net
-(``optimizer_cond`` for the flow steps: ``cond_forward_train`` / ``cond_backward``); the LRNN (the last step's
-condition net: UNet + ConvNeXt, trained with an L2 loss) has no backward here yet.
+Scope: gradients of a flow step's own parameters (the reference's ``optimizer``), of its condition net
+(``optimizer_cond`` for the flow steps: ``cond_forward_train`` / ``cond_backward``) and of the LRNN, the last step's
+network (``lrnn_step_backward``: UNet + mean-volume branch, L1/L2 loss).
 """
 from typing import Dict, List, Optional, Sequence
 
@@ -28,7 +28,7 @@ import torch
 from . import ops
 
 __all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "cond_forward_train", "cond_backward", "unet_forward_train", "unet_backward",
-           "lrnn_forward_train", "lrnn_backward", "allreduce_gradients",
+           "lrnn_forward_train", "lrnn_backward", "lrnn_step_backward", "allreduce_gradients",
            "sgd_step"]
 
 
@@ -516,6 +516,30 @@ def lrnn_backward(tape, g_out):
         _convnext_backward(t1, g_m1, False)
     g_x0 = unet_backward(utape, g_out)                              # dL/dx = g (out = x + ...)
     _conv_param_grads(lrnn.deconv[0], views, g_x0)
+
+
+def lrnn_step_backward(encoder, views, mean_vol, gt, loss_func="L2", group=None):
+    """Training step of the LAST pyramid step (`is_last_step`, CWFA.py:880-886,936-950): upsampled_vol = LRNN(views, mean_vol),
+    loss = F.mse_loss / F.l1_loss(curr_gt, upsampled_vol) (main.py:42: L2), backward into every LRNN parameter.
+    ``encoder`` is the ``Encoder`` (or its ``.net``).  The loss is the mean over the GLOBAL batch when torch.distributed is
+    initialised (gradients are local contributions: ``allreduce_gradients`` sums them).  Returns (loss, upsampled_vol)."""
+    from .CWFA import allreduce_nll
+    lrnn = getattr(encoder, "net", encoder)
+    if loss_func not in ("L1", "L2"):
+        raise NotImplementedError(f"lrnn_step_backward: loss_func {loss_func!r} (L1 and L2 are built)")
+    out, tape = lrnn_forward_train(lrnn, views, mean_vol)
+    cnt = allreduce_nll(torch.tensor([float(out.numel())], dtype=torch.float64, device=out.device), group)
+    numel = float(cnt[0])
+    diff = ops.axpby(out, 1.0, gt, -1.0)
+    if loss_func == "L2":
+        g = ops.axpby(diff, 2.0 / numel)
+        lsum = ops.sample_stats(diff.reshape(1, -1, 1, 1))[1:2]
+    else:
+        g = torch.sign(diff) / numel                      # tiny elementwise glue on the loss gradient
+        lsum = diff.abs().sum(dtype=torch.float64).reshape(1)
+    loss = allreduce_nll(lsum.clone(), group)[0] / numel
+    lrnn_backward(tape, g)
+    return loss, out
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):

@@ -441,3 +441,43 @@ def test_lrnn_mean_branch_backward_golden():
             if not e <= TOL:
                 bad.append((tag + "." + k, e))
     assert not bad, bad
+
+
+def test_full_size_lrnn_step_directional_derivative():
+    """The last pyramid step at BASELINE's size (LRNN on 512x512 views with the mean-volume branch, 63.7 M parameters, L2 loss,
+    CWFA.py:880-886,936-950; stochastic layers off): the central difference of the loss along a random direction in
+    parameter space equals <grad, v> from lrnn_step_backward."""
+    from cwfa_amd import networks as N, training
+    torch.manual_seed(0)
+    enc = N.Encoder(29, 6, 5, 64, True).cuda().train()
+    lr = enc.net
+    lr.deconv[1].drop_out = 0
+    for cn in lr.conv3d:
+        cn.drop_prob = 0.0
+    gen = torch.Generator().manual_seed(21)
+    views = torch.randn(1, 29, 512, 512, generator=gen).cuda()
+    mean = (0.1 * torch.randn(1, 6, 512, 512, generator=gen)).cuda()
+    gt = torch.randn(1, 6, 512, 512, generator=gen).cuda()
+    loss, out = training.lrnn_step_backward(enc, views, mean, gt)
+    assert out.shape == (1, 6, 512, 512)
+    params = [p for p in lr.parameters() if p.grad is not None]
+    assert sum(p.numel() for p in params) > 63e6
+    vs = [torch.randn(p.shape, generator=gen).cuda() * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    slope = sum(float((p.grad.double() * v.double()).sum()) for p, v in zip(params, vs))
+    eps = 1e-2
+
+    def loss_at(sign):
+        with torch.no_grad():
+            for p, v in zip(params, vs):
+                p.add_(v, alpha=sign * eps)
+        try:
+            for p in params:
+                p.grad = None
+            return float(training.lrnn_step_backward(enc, views, mean, gt)[0])
+        finally:
+            with torch.no_grad():
+                for p, v in zip(params, vs):
+                    p.add_(v, alpha=-sign * eps)
+
+    fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
+    assert abs(fd - slope) <= 3e-2 * abs(slope) + 1e-7, (fd, slope, float(loss))
