@@ -64,8 +64,8 @@ def main():
         omega, tape = training.cond_forward_train(cn, views)
         training.cond_backward(tape, c[0])
 
-    ms_c = ev_time(cond_only, reps=3, warm=1)
-    ms_f = ev_time(full_step, reps=3, warm=1)
+    ms_c = ev_time(cond_only, reps=3, warm=2)
+    ms_f = ev_time(full_step, reps=3, warm=2)
     print(f"condition net (29 views -> 48 channels, Conv3d K=32) forward + backward B{B}: {ms_c:.2f} ms; full default training step "
           f"(inverse + forward + backward of the flow step and its condition net): {ms_f:.2f} ms = {B/ms_f*1e3:.2f} volumes/s", flush=True)
     with torch.no_grad():
@@ -93,18 +93,20 @@ def lrnn_time():
     gt = torch.randn(1, 6, 512, 512, generator=gen).cuda()
     params = [p for p in lr.parameters() if p.requires_grad]
 
+    for cn in lr.conv3d:
+        cn.drop_prob = 0.0
+    mean = (0.1 * torch.randn(1, 6, 512, 512, generator=gen)).cuda()
+
     def step():
         for p in params:
             p.grad = None
-        out, tape = training.lrnn_forward_train(lr, views)
-        g = ops.axpby(out, 2.0 / out.numel(), gt, -2.0 / out.numel())          # d mse / d out
-        training.lrnn_backward(tape, g)
+        training.lrnn_step_backward(enc, views, mean, gt)
 
     with torch.no_grad():
-        fwd = ev_time(lambda: lr(views), reps=3, warm=1)
-    ms = ev_time(step, reps=3, warm=1)
+        fwd = ev_time(lambda: lr(views, mean), reps=3, warm=2)
+    ms = ev_time(step, reps=3, warm=2)
     n_par = sum(p.numel() for p in params if p.grad is not None)
-    print(f"LRNN (no mean branch) @512x512 B1: inference forward {fwd:.2f} ms, training step (forward with tape + backward, L2 loss) "
+    print(f"LRNN (UNet 256/512/1024 + mean-volume branch) @512x512 B1: inference forward {fwd:.2f} ms, training step (forward with tape + backward, L2 loss) "
           f"{ms:.2f} ms; {n_par/1e6:.1f} M parameters with gradients; peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 
 
