@@ -252,3 +252,32 @@ def test_full_training_loss_gradients_vs_reference_autograd(name, kind):
     for k in [k[len(f"grad_{kind}/"):] for k in fx if k.startswith(f"grad_{kind}/")]:
         assert_close(sd[k].grad, fx[f"grad_{kind}/" + k], 1e-4 if kind == "l2" else 5e-4, k)
     assert_close(c[0].grad, fx[f"full_{kind}/gc0"], 5e-4, "d loss / d omega")
+
+
+@pytest.mark.parametrize("bias", [0, 1])
+def test_unet_gradients_vs_reference_autograd(bias):
+    """Autograd through the oracle's train-mode UNet against the reference's own gradients (fixture g14)."""
+    fx = load_golden(f"g14_unet_grad_bias{bias}")
+    sd = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd_of(fx).items()}
+    x = T(fx["x"]).requires_grad_()
+    y = O.unet(sd, x, train=True)
+    assert_close(y, fx["y"], 1e-5, "train-mode forward")
+    (y * T(fx["dy"])).sum().backward()
+    assert_close(x.grad, fx["gx"], 1e-4, "input gradient")
+    for k in [k[len("grad/"):] for k in fx if k.startswith("grad/")]:
+        assert_close(sd[k].grad, fx["grad/" + k], 1e-3 if fx["grad/" + k].size == 1 else 1e-4, k)
+
+
+def test_mean_branch_gradients_vs_reference_autograd():
+    """Autograd through the oracle's ConvNeXt / GlobalAttention / combine against the reference's gradients (fixture g15)."""
+    fx = load_golden("g15_meanbranch_grad")
+    sds = {t: {k: v.clone().requires_grad_() for k, v in sd_of(fx, f"sd_{t}/").items()} for t in ("cn1", "cn2", "ga")}
+    mean, x = T(fx["mean"]), T(fx["x"]).requires_grad_()
+    m = O.convnext(sds["cn2"], "", O.convnext(sds["cn1"], "", mean))
+    att = O.global_attention(sds["ga"], "", mean)
+    out = x + m * 2 * (att - 0.5)
+    assert_close(out, fx["out"], 1e-5, "combined output")
+    (out * T(fx["dy"])).sum().backward()
+    for t in ("cn1", "cn2", "ga"):
+        for k in [k[len(f"grad_{t}/"):] for k in fx if k.startswith(f"grad_{t}/")]:
+            assert_close(sds[t][k].grad, fx[f"grad_{t}/" + k], 1e-4, f"{t}.{k}")
