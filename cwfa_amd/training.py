@@ -28,7 +28,7 @@ import torch
 from . import ops
 
 __all__ = ["subnet_forward_train", "subnet_backward", "nll_backward", "step_backward", "cond_forward_train", "cond_backward", "unet_forward_train", "unet_backward",
-           "lrnn_forward_train", "lrnn_backward", "lrnn_step_backward", "allreduce_gradients",
+           "lrnn_forward_train", "lrnn_backward", "lrnn_step_backward", "train_iteration", "allreduce_gradients",
            "sgd_step"]
 
 
@@ -540,6 +540,65 @@ def lrnn_step_backward(encoder, views, mean_vol, gt, loss_func="L2", group=None)
     loss = allreduce_nll(lsum.clone(), group)[0] / numel
     lrnn_backward(tape, g)
     return loss, out
+
+
+def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache, optimizers=None, lr=None, cond_weight=0.40984,
+                    loss_func_reg="L2", loss_func_first_step="L2", z_sampler=None, use_mean_branch=True, group=None):
+    """One training iteration over the whole pyramid for one batch, in the order of the reference's loop (CWFA.py:865-1027):
+    the last step first -- LRNN on the views (+ mean-volume branch), L2 loss against the coarsest level of the ground-truth
+    pyramid -- then every flow step from coarse to fine: condition net, inverse pass from the (detached) previous
+    reconstruction, the weighted reconstruction + NLL loss, backward, gradient exchange, optimiser step, detach
+    (CWFA.py:1015).  ``conv_inn`` / ``cond_nets`` as ``CWFA.build_networks`` returns them (cond_nets[-1] = the LRNN Encoder).
+
+    ``optimizers``: None (plain gradient steps with ``lr``, or no update at all if ``lr`` is None), or one entry per pyramid
+    step n = 0..S-1: a torch optimiser over that step's parameters, or a pair (flow optimiser, condition-net optimiser)
+    as the reference keeps them (``optimizer`` / ``optimizer_cond``).  ``z_sampler(shape) -> tensor`` draws the latent of the
+    inverse pass (None: z = 0, the reference's default temperature, main.py:109).
+    Returns {"losses": per-step full_loss (index = pyramid step), "nll": ..., "recon": ..., "volume": finest reconstruction}."""
+    S = len(conv_inn) + 1
+    gt_cache = [gt_volume]
+    for _ in range(S - 1):                                   # the forward pyramid keeps the low band (CWFA.py:146-195)
+        y = ops.haar1d(gt_cache[-1], False)
+        gt_cache.append(y[:, :y.shape[1] // 2].contiguous())
+
+    def params_of(mods):
+        return [p for m in mods for p in m.parameters() if p.requires_grad]
+
+    def update(n, mods):
+        ps = params_of(mods)
+        allreduce_gradients(ps, group)
+        opt = None if optimizers is None else optimizers[n]
+        if opt is None:
+            if lr is not None:
+                sgd_step(ps, lr)
+        else:
+            for o in (opt if isinstance(opt, (tuple, list)) else (opt,)):
+                if o is not None:
+                    o.step()
+        for p in ps:
+            p.grad = None
+
+    losses, nlls, recons = [None] * S, [None] * S, [None] * S
+    enc = cond_nets[S - 1]
+    for p in params_of([enc]):
+        p.grad = None
+    loss, up = lrnn_step_backward(enc, cond_input, mean_vols_cache[S - 2] if use_mean_branch else None, gt_cache[S - 1],
+                                  loss_func=loss_func_first_step, group=group)
+    losses[S - 1] = recons[S - 1] = loss
+    update(S - 1, [enc])
+    for n in range(S - 2, -1, -1):
+        g, cn = conv_inn[n], cond_nets[n]
+        for p in params_of([g, cn]):
+            p.grad = None
+        omega, ctape = cond_forward_train(cn, cond_input)
+        z = None if z_sampler is None else z_sampler((up.shape[0],) + tuple(g.global_out_shapes[0]))
+        out = step_backward(g, gt_cache[n], [omega, mean_vols_cache[n]], low=up, z=z, cond_weight=cond_weight,
+                            loss_func=loss_func_reg, group=group, want_cond_grads=True)
+        cond_backward(ctape, out["cond_grads"][0])
+        losses[n], nlls[n], recons[n] = out["full_loss"], out["nll"], out["recon"]
+        update(n, [g, cn])
+        up = out["xhat"]                                     # `upsampled_vol.detach()`: nothing here records a graph
+    return {"losses": losses, "nll": nlls, "recon": recons, "volume": up}
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):

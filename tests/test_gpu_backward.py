@@ -481,3 +481,35 @@ def test_full_size_lrnn_step_directional_derivative():
 
     fd = (loss_at(+1) - loss_at(-1)) / (2 * eps)
     assert abs(fd - slope) <= 3e-2 * abs(slope) + 1e-7, (fd, slope, float(loss))
+
+
+def test_full_size_training_iteration_reduces_the_loss():
+    """The whole pyramid at BASELINE's size (512x512x96: LRNN + 4 flow steps with their condition nets, 67 M parameters), the
+    reference's per-step order (CWFA.py:865-1027), torch.optim.Adam as the optimiser on the plain Parameters / .grad
+    tensors: three iterations on one synthetic batch lower every step's loss."""
+    from cwfa_amd import CWFA, training
+    torch.manual_seed(0)
+    np_seed = 0
+    import numpy as np
+    np.random.seed(np_seed)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 5, with_lrnn=True, device="cuda")
+    enc = cond_nets[-1]
+    enc.net.deconv[1].drop_out = 0
+    for cn in enc.net.conv3d:
+        cn.drop_prob = 0.0
+    gen = torch.Generator().manual_seed(31)
+    gt = torch.randn(1, 96, 512, 512, generator=gen).cuda()
+    views = torch.randn(1, 29, 512, 512, generator=gen).cuda()
+    means = [(0.1 * torch.randn(1, 96 // 2 ** (n + 1), 512, 512, generator=gen)).cuda() for n in range(4)]
+    opts = []
+    for n in range(5):
+        mods = [cond_nets[n]] if n == 4 else [conv_inn[n], cond_nets[n]]
+        opts.append(torch.optim.Adam([p for m in mods for p in m.parameters() if p.requires_grad], lr=1e-4))
+    hist = []
+    for _ in range(3):
+        res = training.train_iteration(conv_inn, cond_nets, gt, views, means, optimizers=opts)
+        hist.append([float(v) for v in res["losses"]])
+    assert res["volume"].shape == (1, 96, 512, 512)
+    assert all(np.isfinite(h).all() for h in hist), hist
+    for n in range(5):
+        assert hist[-1][n] < hist[0][n], (n, hist)
