@@ -254,7 +254,7 @@ def main():
                 res["experiment_bf16"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_lrnn and not a.no_experiment:
             try:
-                res["experiment_train_step"] = train_experiment(conv_inn, dev, a, max(a.steps // 4, 3))
+                res["experiment_train_step"] = train_experiment(conv_inn, cond_nets, dev, a, max(a.steps // 4, 3))
             except Exception as exc:                          # noqa: BLE001
                 res["experiment_train_step"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
@@ -329,44 +329,32 @@ def bf16_experiment(ops, step, steps, batch):
                     "tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle"}
 
 
-def train_experiment(conv_inn, dev, a, steps):
-    """NOT the headline: SURVEY.md 8(f) row 1 -- one training step (inverse + forward with tape + backward, CWFA.py:905-1006) of
-    the finest flow step (D_0 -> 48 flow channels, 5 CAT blocks) on one synthetic volume, conditions as inputs, measured
-    after the timed region."""
+def train_experiment(conv_inn, cond_nets, dev, a, steps):
+    """NOT the headline: SURVEY.md 8(f) row 1 -- one training iteration over the WHOLE pyramid on one synthetic volume, in
+    the reference's order (CWFA.py:865-1027): LRNN step (L2), then the four flow steps with their condition nets (inverse +
+    forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  After the timed region."""
     from cwfa_amd import training
-    g = conv_inn[0]
-    was_training = g.training
-    g.train()
     B, D, S = 1, a.depths, a.side
     gen = torch.Generator().manual_seed(17)
-    x = torch.randn(B, D, S, S, generator=gen).to(dev)
-    c = [torch.randn(B, D // 2, S, S, generator=gen).to(dev), (0.1 * torch.randn(B, D // 2, S, S, generator=gen)).to(dev)]
-    params = [p for p in g.parameters() if p.requires_grad]
+    gt = torch.randn(B, D, S, S, generator=gen).to(dev)
+    views = torch.randn(B, 29, S, S, generator=gen).to(dev)
+    means = [(0.1 * torch.randn(B, D // 2 ** (n + 1), S, S, generator=gen)).to(dev) for n in range(len(conv_inn))]
 
-    low = torch.randn(B, D // 2, S, S, generator=gen).to(dev)
+    def one():
+        return training.train_iteration(conv_inn, cond_nets, gt, views, means)
 
-    def one():                                   # the default loss: 0.40984 * mse(gt, xhat(z = 0)) + 0.59016 * NLL (main.py:43,107)
-        for p in params:
-            p.grad = None
-        return training.step_backward(g, x, c, low=low)["full_loss"]
-
-    try:
-        one(); one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            nll = one()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        n_par = sum(p.numel() for p in params if p.grad is not None)
-    finally:
-        for p in params:
-            p.grad = None
-        g.train(was_training)
-    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "full_loss": float(nll),
-            "parameters_with_gradients": n_par,
-            "note": "flow step 0 only, conditions given; gradients of the step's own parameters pinned to the reference's "
-                    "autograd by tests/test_gpu_backward.py (fixture g13)"}
+    one(); one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_par = sum(p.numel() for m in list(conv_inn) + list(cond_nets) for p in m.parameters() if p.requires_grad)
+    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps,
+            "full_loss_per_pyramid_step": [float(v) for v in res["losses"]], "trainable_parameters": n_par,
+            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; gradients pinned to the reference's autograd "
+                    "by tests/test_gpu_backward.py (fixtures g13-g15)"}
 
 
 def pmc_traffic(dom, a):
