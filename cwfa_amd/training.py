@@ -21,7 +21,7 @@ Scope: gradients of a flow step's own parameters (the reference's ``optimizer``)
 (``optimizer_cond`` for the flow steps: ``cond_forward_train`` / ``cond_backward``) and of the LRNN, the last step's
 network (``lrnn_step_backward``: UNet + mean-volume branch, L1/L2 loss).
 """
-from typing import Dict, List, Optional, Sequence
+from typing import Sequence
 
 import torch
 
@@ -445,7 +445,6 @@ def unet_backward(tape, g_out):
 
 def _convnext_forward_train(cn, x):
     """ConvNeXt (networks.py:468-503): u = 1x1(x); out = GELU(1x1(LayerNorm_{C,H,W}(7x7(u)))) + drop_path(u), unfused."""
-    from .networks import drop_path
     P = cn._packed.get
     u = ops.conv2d(x, P(cn.input), bias=cn.input.bias)
     v = ops.conv2d(u, P(cn.m[0]), bias=cn.m[0].bias)

@@ -4,7 +4,6 @@ configs[3]'s per-rank shape (512x512x96 volumes) and the weight-gradient kernel 
     python tools/train_time.py [batch]"""
 import os
 import sys
-import time
 
 import torch
 
