@@ -49,6 +49,7 @@ struct WgCfg {
     static constexpr int BUFW = XW + DW;
     static constexpr int LDS_BYTES = 2 * BUFW * 4;
     static constexpr int XLOADS = 64 * XR / 8;                        // core columns: (ci,row) pairs / 8 per pass
+    static_assert(8 % XR == 0, "the staging map steps whole channels per pass");
     static constexpr int HLOADS = 64 * XR * 2 * PADW / 256;             // halo columns (2 * PADW of them)
 };
 
@@ -75,14 +76,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
                                                           (int)((unsigned)min(64, p.Cin - ci0) * HW4), 0x00020000);
         const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (int64_t)b * p.dy_bs + (int64_t)co0 * HW), 0,
                                                           (int)((unsigned)min(64, p.Cout - co0) * HW4), 0x00020000);
-        {   // x, core columns: pair q = sq + 8 j -> ci = q / XR, row = q % XR
-            const int gc = c0 + scol;
+        {   // x, core columns: pair q = sq + 8 j -> ci = q / XR, row = q % XR.  8 is a multiple of XR, so the row (and with it
+            // the validity) is the same for every j and the channel advances by 8 / XR: one compare, then one add per load
+            // (the out-of-range marker survives the adds: 64 * HW4 < 2^31)
+            const int gc = c0 + scol, r = sq % C::XR;
+            const int gr = r0 + r - C::PADH + p.row_off;
+            unsigned off = (gr >= 0 && gr < p.H && gc < p.W) ? (unsigned)(sq / C::XR) * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
 #pragma unroll
             for (int j = 0; j < C::XLOADS; ++j) {
-                const int q = sq + 8 * j, ci = q / C::XR, r = q % C::XR;
-                const int gr = r0 + r - C::PADH + p.row_off;
-                const unsigned off = (gr >= 0 && gr < p.H && gc < p.W) ? (unsigned)ci * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
                 xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+                off += (unsigned)(8 / C::XR) * HW4;
             }
         }
         if constexpr (C::HLOADS > 0) {      // x, the 2 * PADW halo columns: entry e = tid + 256 j -> (pair = (ci, row), halo column)
@@ -97,14 +100,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
                 hr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
             }
         }
-        {   // dy: pair q = sq + 8 j -> co = q / 2, row = q % 2
-            const int gc = c0 + scol;
+        {   // dy: pair q = sq + 8 j -> co = q / 2, row = q % 2: same structure, the channel advances by 4
+            const int gc = c0 + scol, gr = r0 + (sq & 1);
+            unsigned off = (gr < p.H && gc < p.W) ? (unsigned)(sq >> 1) * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int q = sq + 8 * j, co = q >> 1, r = q & 1;
-                const int gr = r0 + r;
-                const unsigned off = (gr < p.H && gc < p.W) ? (unsigned)co * HW4 + (unsigned)(gr * p.W + gc) * 4u : OOB;
                 dr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+                off += 4u * HW4;
             }
         }
     };
