@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
     __syncthreads();
     for (; strip < p.nstrips; strip += gridDim.x) {
         const int next = strip + gridDim.x;
+#ifdef CWFA_EXP_WG_NOSTAGE
+        const bool more = false;
+#else
         const bool more = next < p.nstrips;
+#endif
         if (more) issue(next);
         const float* xs = smem + buf * C::BUFW + kh * WG_CHP + cit * 32 + l31;
         const float* ds = smem + buf * C::BUFW + C::XW + kh * WG_CHP + mt * 32 + l31;
@@ -158,9 +162,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
         auto fetch = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int row = s / 16, col = (2 * s) % 32;
+#ifdef CWFA_EXP_WG_NOLDS
+            av[s & 1] = (float)(s + lane);
+#pragma unroll
+            for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = (float)(i + s);
+#else
             av[s & 1] = ds[(2 * s) * WG_CHP];
 #pragma unroll
             for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = xs[((row + i / KW) * C::XC + col + i % KW) * WG_CHP];
+#endif
         };
         fetch(std::integral_constant<int, 0>{});
         static_for<32>([&](auto sc) {
@@ -168,7 +178,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
             if constexpr (s + 1 < 32) fetch(std::integral_constant<int, s + 1>{});
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+#ifdef CWFA_EXP_WG_NOMFMA
+            for (int i = 0; i < C::TAPS; ++i) acc[i][0] += av[s & 1] * bv[s & 1][i];
+#else
             for (int i = 0; i < C::TAPS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][i], acc[i], 0, 0, 0);
+#endif
             bacc += av[s & 1];
             __builtin_amdgcn_sched_barrier(0);
         });
