@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {"base": [], "nostage": ["-DCWFA_EXP_WG_NOSTAGE"], "nomfma": ["-DCWFA_EXP_WG_NOMFMA"],
-            "nostage_nolds": ["-DCWFA_EXP_WG_NOSTAGE", "-DCWFA_EXP_WG_NOLDS"]}
+            "nostage_nolds": ["-DCWFA_EXP_WG_NOSTAGE", "-DCWFA_EXP_WG_NOLDS"],
+            "burst": ["-DCWFA_EXP_WG_BURST"]}
 
 
 def build():
