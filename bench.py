@@ -37,9 +37,25 @@ def family(key):
         return "wino_layer_kernel"
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
+    if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
+        return "conv3x3_wino2d_kernel[%s]" % tag
     if ks == 3 and cout >= 33:
         return "conv3x3_wino_kernel<%s>[%s]" % ("W64" if cout <= 64 else "W128", tag)
     return "conv2d_mfma_kernel<k%d,%s>[%s]" % (ks, "co<=32" if cout <= 32 else "co<=64" if cout <= 64 else "co>64", tag)
+
+
+WINO2D_MIN = 512      # the library's "winograd_2d" default (ops.WINOGRAD_2D_DEFAULT); --wino2d overrides both
+
+
+def issued_factor(fam):
+    """MFMA work actually issued / algorithmic FLOPs of a kernel family (Winograd kernels issue fewer)."""
+    if fam == "wino_layer_kernel":
+        return 0.7                     # nine F(2,3) taps (x 2/3) + one direct 1x1 tap, of ten algorithmic
+    if "wino2d" in fam:
+        return 4.0 / 9.0               # F(2x2,3x3): 16 products per 4 outputs instead of 36
+    if "wino" in fam:
+        return 2.0 / 3.0               # F(2,3) along one axis
+    return 1.0
 
 
 # family -> substring of the kernel's name in a rocprofv3 trace (template arguments: config, epilogue id, prologue flag)
@@ -49,6 +65,7 @@ ROCPROF_NAMES = {
     "conv3x3_wino_kernel<W128>[|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, false>",
     "conv3x3_wino_kernel<W128>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 2, false>",
     "conv3x3_wino_kernel<W64>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 1, 8>, 2, false>",
+    "conv3x3_wino2d_kernel[|prelu|||]": "conv3x3_wino2d_kernel<3, false, true>",
 }
 
 
@@ -100,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
     ap.add_argument("--no-experiment", action="store_true", help="skip the extra split-bf16 measurement after the timed region")
+    ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
+    ap.add_argument("--no-materialize", action="store_true", help="(tuning) UNet BatchNorm applied on load instead of materialised")
     ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[4] (NOT the headline configuration): bf16 operands in "
                     "the heavy convolutions, fp32 accumulation; the line's dtype says so")
     ap.add_argument("--split-bf16", type=int, default=0, choices=(0, 1, 2),
@@ -128,6 +147,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     from cwfa_amd import CWFA, ops
+    if a.wino2d is not None:
+        global WINO2D_MIN
+        WINO2D_MIN = a.wino2d
+        ops.set_option("winograd_2d", a.wino2d)
+    if a.no_materialize:
+        from cwfa_amd import unet as _unet
+        _unet._MATERIALIZE = False
     if a.bf16:
         ops.set_precision("bf16")
         a.split_bf16 = 2
@@ -210,9 +236,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "kernel": dom + (" (v_mfma_f32_32x32x16_bf16, six split products per algorithmic FMA)" if "split" in dom else
-                                          " (v_mfma_f32_32x32x2_f32" + (", Winograd F(2,3): 1.5x fewer MFMAs than the "
-                                          "algorithmic count" if "wino" in dom else "") + ")"),
-                         "mfma_issued_frac": tf / (1.5 if "wino" in dom else 1.0) / PEAK_FP32_MFMA_TFLOPS,
+                                          " (v_mfma_f32_32x32x2_f32" + (", Winograd: %.2fx the algorithmic MFMA count is issued"
+                                                                         % issued_factor(dom) if "wino" in dom else "") + ")"),
+                         "mfma_issued_frac": tf * issued_factor(dom) / PEAK_FP32_MFMA_TFLOPS,
                          "shapes": [dict(zip(("ks", "cin", "cout", "H", "W", "B", "launches"), (*k[:6], n)))
                                     for k, n in sorted(shapes.items(), key=lambda kv: -kv[1])],
                          "flops_per_launch": f_dom / n_dom, "algorithmic_bytes_per_launch": alg_bytes,
@@ -234,8 +260,7 @@ def main():
             res["roofline_second"] = {"bound": "mfma", "achieved": tf2, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tf2 / PEAK_FP32_MFMA_TFLOPS, "traffic": tr2, "kernel": ranked[1],
                                       # issued / algorithmic MFMA work: 2/3 for Winograd 3x3; the fused layer = 9 Winograd taps + 1 direct tap of 10
-                                      "mfma_issued_frac": tf2 * (0.7 if ranked[1] == "wino_layer_kernel" else
-                                                                 2 / 3 if "wino" in ranked[1] else 1.0) / PEAK_FP32_MFMA_TFLOPS,
+                                      "mfma_issued_frac": tf2 * issued_factor(ranked[1]) / PEAK_FP32_MFMA_TFLOPS,
                                       "flops_per_launch": f2 / n2, "avg_launch_ms": t2 / n2, "launches_timed": n2,
                                       "algorithmic_bytes_per_launch": sum(conv_bytes(k) * n for k, n in sh2.items()) / n2,
                                       "share_of_conv_time": tot[ranked[1]][0] / all_conv_ms}

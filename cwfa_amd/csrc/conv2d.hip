@@ -1578,7 +1578,7 @@ extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* w3_split,
 }
 
 int g_cwfa_wino_min_cout = 1;
-int g_cwfa_wino_2d = 0;
+int g_cwfa_wino_2d = 512;     // 2-D F(2x2,3x3) for >= 512 output channels (the UNet's plain convolutions), see conv_internal.h
 
 extern "C" int cwfa_set_option(const char* name, int value) {
     CWFA_REQUIRE(name, CWFA_E_INVAL, "cwfa_set_option: null name");

@@ -8,9 +8,10 @@
 extern int g_cwfa_wino_min_cout;
 static inline bool cwfa_wino_selected(int ks, int Cout) { return ks == 3 && Cout >= g_cwfa_wino_min_cout; }
 
-// layers with more than 64 output channels take the 2-D F(2x2,3x3) kernel (conv_wino2d.hip) when "winograd_2d" is set
+// "winograd_2d" = v: layers with more than 64 and at least v output channels take the 2-D F(2x2,3x3) kernel
+// (conv_wino2d.hip); 0 = never
 extern int g_cwfa_wino_2d;
-static inline bool cwfa_wino2d_selected(int Cout) { return g_cwfa_wino_2d != 0 && Cout > 64; }
+static inline bool cwfa_wino2d_selected(int Cout) { return g_cwfa_wino_2d != 0 && Cout > 64 && Cout >= g_cwfa_wino_2d; }
 int64_t cwfa_wino2d_packed_floats(int Cout, int Cin);
 int cwfa_wino2d_pack(const float* w, float* packed, int Cout, int Cin, hipStream_t stream);
 int cwfa_wino2d_conv(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int64_t x_bs,

@@ -779,6 +779,9 @@ def pack_epoch():
     return _pack_epoch
 
 
+WINOGRAD_2D_DEFAULT = 512     # library default of the "winograd_2d" option (output-channel threshold of the 2-D kernel)
+
+
 def set_option(name, value):
     """Process-wide tuning option (see cwfa_set_option in include/cwfa_hip.h).  Filter banks packed before a change of
     "winograd_min_cout" / "winograd_2d" / "split_bf16" must be re-packed.

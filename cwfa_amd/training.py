@@ -60,17 +60,16 @@ def subnet_forward_train(net, u, conv_in, conv_out):
     return ops.conv2d(b, P(conv_out), bias=conv_out.bias), tape
 
 
-_packT_cache = {}
-
-
 def _packT(conv):
-    """Filter bank of the data-gradient convolution: W^T[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx], in kernel layout."""
+    """Filter bank of the data-gradient convolution: W^T[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx], in kernel layout.
+    Cached ON the module (a process-wide table keyed by id() would outlive the module and could hand a later module that
+    happens to reuse the id, the version counter and the storage address somebody else's filter bank)."""
     w = conv.weight
-    key = id(conv)
-    hit = _packT_cache.get(key)
+    hit = getattr(conv, "_cwfa_packT", None)
     if hit is None or hit[1] != w._version or hit[2] != w.data_ptr() or hit[0].epoch != ops.pack_epoch():
         wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()
-        hit = _packT_cache[key] = (ops.pack_conv_weight(wt), w._version, w.data_ptr())
+        hit = (ops.pack_conv_weight(wt), w._version, w.data_ptr())
+        object.__setattr__(conv, "_cwfa_packT", hit)
     return hit[0]
 
 
@@ -396,17 +395,14 @@ def unet_forward_train(unet, x):
     return t.out, t
 
 
-_packT4_cache = {}
-
-
 def _packT4(convT):
     """1x1 filter bank of a ConvTranspose2d(k2,s2)'s data gradient: [Cin][Co*4] (cout index c*4 + dy*2 + dx, as the forward)."""
     w = convT.weight
-    hit = _packT4_cache.get(id(convT))
+    hit = getattr(convT, "_cwfa_packT", None)
     if hit is None or hit[1] != w._version or hit[2] != w.data_ptr() or hit[0].epoch != ops.pack_epoch():
         cin = w.shape[0]
-        hit = _packT4_cache[id(convT)] = (ops.pack_conv_weight(w.detach().reshape(cin, -1, 1, 1).contiguous()), w._version,
-                                          w.data_ptr())
+        hit = (ops.pack_conv_weight(w.detach().reshape(cin, -1, 1, 1).contiguous()), w._version, w.data_ptr())
+        object.__setattr__(convT, "_cwfa_packT", hit)
     return hit[0]
 
 

@@ -22,6 +22,9 @@ from . import ops
 __all__ = ["UNet", "UNetConvBlock", "UNetUpBlock"]
 
 
+_MATERIALIZE = True      # see UNetConvBlock.run (False: BatchNorm applied inside the consumer convolution's load)
+
+
 class _Packed:
     """Cache of kernel-layout filter banks keyed by the parameter they were built from."""
 
@@ -102,8 +105,15 @@ class UNetConvBlock(nn.Module):
         for li, (conv, act, bn) in enumerate(layers):
             kind, alpha = self._act(act)
             sc, sh = aff if aff is not None else (None, None)
+            add = in_add if li == 0 else None
+            if _MATERIALIZE and (sc is not None or add is not None) and (x.shape[2] * x.shape[3]) % 4 == 0:
+                # one streaming pass writes the BatchNorm (x mask, + skip) output, and the convolution runs without its
+                # load-side prologue: the plain kernels are 8-10 % faster than the prologue ones and the 2-D Winograd
+                # kernel (x1.2 on the 512 / 1024-channel layers) only pays off without it -- the pass costs 2-7 %
+                x = ops.plane_affine(x, sc, sh, add=add)
+                sc = sh = add = None
             x = ops.conv2d(x, self._packed.get(conv), bias=conv.bias, act=kind, prelu_alpha=alpha, in_scale=sc,
-                           in_shift=sh, in_add=in_add if li == 0 else None)
+                           in_shift=sh, in_add=add)
             last = li == len(layers) - 1
             m = out_mask if last else None
             if bn is not None:

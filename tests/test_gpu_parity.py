@@ -218,7 +218,7 @@ def _winograd_case(ops, two_d, x, w, b, res, alpha, sc, sh, add, want):
                                       in_add=add.cuda()),
         }
     finally:
-        ops.set_option("winograd_2d", 0)
+        ops.set_option("winograd_2d", ops.WINOGRAD_2D_DEFAULT)
     for k in want:
         assert_close(got[k], want[k], 5e-6, f"winograd (2-D {two_d}) {k}")
 
