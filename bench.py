@@ -65,7 +65,7 @@ ROCPROF_NAMES = {
     "conv3x3_wino_kernel<W128>[|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, false>",
     "conv3x3_wino_kernel<W128>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 2, false>",
     "conv3x3_wino_kernel<W64>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 1, 8>, 2, false>",
-    "conv3x3_wino2d_kernel[|prelu|||]": "conv3x3_wino2d_kernel<3, false, true>",
+    "conv3x3_wino2d_kernel[|prelu|||]": "conv3x3_wino2d_kernel<2, false, true>",
 }
 
 
