@@ -106,7 +106,8 @@ class UNetConvBlock(nn.Module):
             kind, alpha = self._act(act)
             sc, sh = aff if aff is not None else (None, None)
             add = in_add if li == 0 else None
-            if _MATERIALIZE and (sc is not None or add is not None) and (x.shape[2] * x.shape[3]) % 4 == 0:
+            if (_MATERIALIZE and ops._split_bf16 < 2 and (sc is not None or add is not None)
+                    and (x.shape[2] * x.shape[3]) % 4 == 0):         # (the split / bf16 kernels apply the prologue for free)
                 # one streaming pass writes the BatchNorm (x mask, + skip) output, and the convolution runs without its
                 # load-side prologue: the plain kernels are 8-10 % faster than the prologue ones and the 2-D Winograd
                 # kernel (x1.2 on the 512 / 1024-channel layers) only pays off without it -- the pass costs 2-7 %
