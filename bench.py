@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
     ap.add_argument("--no-experiment", action="store_true", help="skip the extra split-bf16 measurement after the timed region")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
+    ap.add_argument("--no-materialize-up", action="store_true", help="(tuning) the same for the UNet's transposed convolutions")
     ap.add_argument("--no-materialize", action="store_true", help="(tuning) UNet BatchNorm applied on load instead of materialised")
     ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[4] (NOT the headline configuration): bf16 operands in "
                     "the heavy convolutions, fp32 accumulation; the line's dtype says so")
@@ -154,6 +155,9 @@ def main():
     if a.no_materialize:
         from cwfa_amd import unet as _unet
         _unet._MATERIALIZE = False
+    if a.no_materialize_up:
+        from cwfa_amd import unet as _unet
+        _unet._MATERIALIZE_UP = False
     if a.bf16:
         ops.set_precision("bf16")
         a.split_bf16 = 2

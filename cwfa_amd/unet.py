@@ -22,6 +22,7 @@ from . import ops
 __all__ = ["UNet", "UNetConvBlock", "UNetUpBlock"]
 
 
+_MATERIALIZE_UP = False  # the same for the transposed convolutions of the up path: measured, no gain (tools/bench_variants.sh)
 _MATERIALIZE = True      # see UNetConvBlock.run (False: BatchNorm applied inside the consumer convolution's load)
 
 
@@ -154,6 +155,9 @@ class UNetUpBlock(nn.Module):
 
     def run(self, x, bridge, in_affine=None, out_mask=None):
         sc, sh = in_affine if in_affine is not None else (None, None)
+        if _MATERIALIZE_UP and ops._split_bf16 < 1 and sc is not None and (x.shape[2] * x.shape[3]) % 4 == 0:
+            x = ops.plane_affine(x, sc, sh)
+            sc = sh = None
         up = ops.conv2d(x, self._packed.get(self.up, transposed=True), bias=self.up.bias, in_scale=sc, in_shift=sh)
         add = self.center_crop(bridge, up.shape[2:]) if self.skip_conn else None
         return self.conv_block.run(up, in_add=add, out_mask=out_mask)
