@@ -14,12 +14,20 @@ rest = sum(float(x["TotalDurationNs"]) for x in rows[14:]) / steps / 1e6
 table = ("| kernel | launches / volume | ms / volume | % |\n|---|---|---|---|\n" + "\n".join(lines) +
          "\n| (%d smaller kernels) | | %.2f | %.1f |\n| total | | %.2f | 100 |" % (len(rows) - 14, rest, 100 * rest / tot, tot))
 cb = d["cpu_baseline"]
+dom = r["kernel"].split(" (")[0]
+nshapes = len(r.get("shapes", []))
+if dom == "wino_layer_kernel":
+    kdesc = "the fused residual layer of the coupling sub-networks, 64 channels @512², 60 launches per volume"
+    tdesc = "the remaining factor is the row halo of the tile (the 3x3 reads 6 rows for 4) where it misses L2, and the filter panels."
+else:
+    kdesc = f"UNet 3×3 convs, {nshapes} shapes"
+    tdesc = "the remaining factor is the row halo of a 4-row tile and the second read by the other cout tiles where it misses L2; before the XCD-aware tile map it was 11x."
 block = f"""<!-- RESULTS:BEGIN (tools/refresh_results.py) -->
-| r01 v3 (Winograd F(2,3), in-stream staging, buffer loads, MFMA Conv3d, XCD-aware tiles) | {d['value']:.1f} | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` (UNet 3×3 convs, 5 shapes, BatchNorm-on-load with/without skip add) | {r['achieved']:.1f} ({r['frac']:.2f}; matrix pipe {r['mfma_issued_frac']:.2f}) | {d['roofline_dwt']['achieved']:.0f} ({d['roofline_dwt']['frac']:.2f}) |
+| r01 v3 (Winograd F(2,3) / F(2×2,3×3), in-stream staging, buffer loads, MFMA Conv3d, XCD-aware tiles, materialised BatchNorm outputs) | {d['value']:.1f} | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` ({kdesc}) | {r['achieved']:.1f} ({r['frac']:.2f}; matrix pipe {r['mfma_issued_frac']:.2f}) | {d['roofline_dwt']['achieved']:.0f} ({d['roofline_dwt']['frac']:.2f}) |
 
 CPU baseline (oracle, torch CPU, all host cores): {cb['value']:.4f} volumes/s on {cb['cores']} cores ({cb['sample']}) — GPU/CPU = {d['value'] / cb['value']:.0f}×; reported for context, the roofline fraction is the figure of merit.
 
-Dominant kernel traffic (`profiles/r01_v3_pmc_traffic.json`): {r['traffic'] / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (inputs incl. skip tensor once + output once) — the remaining factor is the 1.5× row halo of a 4-row tile and the second read by the other cout tile where it misses L2; before the XCD-aware tile map it was 1507 MB.  `avg_launch_ms` {r['avg_launch_ms']:.3f} (HIP events, bench.py) vs {float(rows[0]['AverageNs']) / 1e6:.3f} (rocprofv3 average of the same kernel).
+Dominant kernel traffic (`profiles/r01_v3_pmc_traffic.json`): {r['traffic'] / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (input once + output once) — {tdesc}  `avg_launch_ms` {r['avg_launch_ms']:.3f} (HIP events, bench.py) vs {float(rows[0]['AverageNs']) / 1e6:.3f} (rocprofv3 average of the same kernel).
 
 Per-kernel time per volume, r01 v3 (rocprofv3 `--kernel-trace --stats`, `profiles/r01_v3_bench_kernel_stats.csv`):
 {table}
