@@ -18,6 +18,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -284,6 +285,167 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(y + b * y_bs + i) = o;
 }
 
+// ---- 3x3 weight gradient, second form (images whose rows are 16-byte aligned: W % 4 == 0): pixel-minor tiles filled by
+// LDS-DMA.  Same block / wave / accumulator layout as conv_wgrad_kernel<3,3>, but
+//   * the x tile is [64 ci][4 rows][40 px] (image columns c0-4 .. c0+35) + one pad chunk per channel (164 words: 41
+//     sixteen-byte chunks, odd, so the 32 lanes of a ds_read_b128 hit 32 different 16-byte bank groups), the dy tile
+//     [64 co][2 rows][32 px] + pad (68 words); both arrive by `buffer_load ... lds` (16 bytes per lane, zeros outside the
+//     image from the range check): 14 or 15 DMA instructions per wave and strip, no staging registers, no ds_write;
+//   * the MFMA k index pairs the strip's two ROWS (kh) and a k-step is one column, so a lane's operands of consecutive
+//     k-steps are consecutive words: one ds_read_b128 of dy and three of x (one per tap row; the three taps of a row slide
+//     over a 12-pixel register window) feed FOUR k-steps = 36 MFMAs, where the first form issues 28 LDS reads.
+namespace wr {
+constexpr int XCH = 10, XCI = 4 * XCH + 1, XCHUNKS = 64 * XCI;      // chunks (16 B) per tile row / per channel / per tile
+constexpr int DCO = 2 * 8 + 1, DCHUNKS = 64 * DCO;
+constexpr int XINSTR = XCHUNKS / 64, DINSTR = DCHUNKS / 64;         // 41 + 17 wave-wide DMA instructions per strip
+constexpr int BUFB = (XCHUNKS + DCHUNKS) * 16, LDS_BYTES = 2 * BUFB;
+constexpr int XSLOTS = (XINSTR + 3) / 4, DSLOTS = (DINSTR + 3) / 4; // per wave
+static_assert(XCHUNKS % 64 == 0 && DCHUNKS % 64 == 0, "whole wave instructions");
+}  // namespace wr
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(WgParams p) {
+    using namespace wr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int mt = wave & 1, cit = wave >> 1;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int64_t HW = (int64_t)p.H * p.W;
+    const unsigned HW4 = (unsigned)HW * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // DMA roles: slot j of this wave is wave instruction q = wave + 4 j; lane -> chunk g = 64 q + lane of the tile
+    unsigned xrel[XSLOTS], drel[DSLOTS];       // byte offset relative to the strip origin (row r0, column c0)
+    int xrc[XSLOTS], drc[DSLOTS];              // row | column chunk << 4 | (a real chunk, not a pad) << 8
+#pragma unroll
+    for (int j = 0; j < XSLOTS; ++j) {
+        const int g = 64 * (wave + 4 * j) + lane, ci = g / XCI, rem = g % XCI, row = rem / XCH, cc = rem % XCH;
+        const bool real = wave + 4 * j < XINSTR && rem < 4 * XCH;
+        xrel[j] = (unsigned)ci * HW4 + (unsigned)(((row - 1) * p.W + 4 * cc - 4) * 4);
+        xrc[j] = row | (cc << 4) | ((int)real << 8);
+    }
+#pragma unroll
+    for (int j = 0; j < DSLOTS; ++j) {
+        const int g = 64 * (wave + 4 * j) + lane, co = g / DCO, rem = g % DCO, row = rem / 8, cc = rem % 8;
+        const bool real = wave + 4 * j < DINSTR && rem < 16;
+        drel[j] = (unsigned)co * HW4 + (unsigned)((row * p.W + 4 * cc) * 4);
+        drc[j] = row | (cc << 4) | ((int)real << 8);
+    }
+    auto issue = [&](int strip, int buf) {
+        const int b = strip / (p.sy * p.sx), rem = strip - b * (p.sy * p.sx);
+        const int r0 = (rem / p.sx) * 2, c0 = (rem % p.sx) * 32;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)b * p.x_bs + (int64_t)ci0 * HW), 0,
+                                                          (int)((unsigned)min(64, p.Cin - ci0) * HW4), 0x00020000);
+        const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (int64_t)b * p.dy_bs + (int64_t)co0 * HW), 0,
+                                                          (int)((unsigned)min(64, p.Cout - co0) * HW4), 0x00020000);
+        const unsigned origin = (unsigned)((r0 * p.W + c0) * 4);
+        // tile rows r0-1 .. r0+2 and column chunks c0-4+4cc: which of them lie inside the image
+        const int rmin = r0 == 0 ? 1 : 0, rmax = min(3, p.H - r0), cmin = c0 == 0 ? 1 : 0, cmax = min(XCH - 1, (p.W - c0) / 4);
+        char* xb = lds + buf * BUFB;
+#pragma unroll
+        for (int j = 0; j < XSLOTS; ++j) {
+            if (wave + 4 * j < XINSTR) {
+                const int row = xrc[j] & 15, cc = (xrc[j] >> 4) & 15;
+                const bool ok = (xrc[j] >> 8) && row >= rmin && row <= rmax && cc >= cmin && cc <= cmax;
+                const unsigned off = ok ? origin + xrel[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(xb + (wave + 4 * j) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+        const int drmax = min(1, p.H - 1 - r0), dcmax = min(7, (p.W - c0) / 4 - 1);
+        char* db = xb + XCHUNKS * 16;
+#pragma unroll
+        for (int j = 0; j < DSLOTS; ++j) {
+            if (wave + 4 * j < DINSTR) {
+                const int row = drc[j] & 15, cc = (drc[j] >> 4) & 15;
+                const bool ok = (drc[j] >> 8) && row <= drmax && cc <= dcmax;
+                const unsigned off = ok ? origin + drel[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr)(db + (wave + 4 * j) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bacc = 0.f;
+
+    int strip = blockIdx.x, buf = 0;
+    if (strip < p.nstrips) issue(strip, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; strip < p.nstrips; strip += gridDim.x) {
+        const int next = strip + gridDim.x;
+        if (next < p.nstrips) issue(next, buf ^ 1);
+        // this lane's operand rows: A = dy[co][row kh], B(ky) = x[ci][tile row kh + ky]
+        const f32x4* ap = reinterpret_cast<const f32x4*>(lds + buf * BUFB + XCHUNKS * 16) + (mt * 32 + l31) * DCO + kh * 8;
+        const f32x4* bp = reinterpret_cast<const f32x4*>(lds + buf * BUFB) + (cit * 32 + l31) * XCI + kh * XCH;
+        f32x4 win[3][3], av, nwin[3], nav;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) win[ky][c] = bp[ky * XCH + c];
+        av = ap[0];
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // output column 4j + e sits at tile column t = 4(j+1) + e; taps read t-1, t, t+1 of the three tile rows
+                const float a = av[e];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float b0 = e == 0 ? win[ky][0][3] : win[ky][1][e - 1];
+                    const float b1 = win[ky][1][e];
+                    const float b2 = e == 3 ? win[ky][2][0] : win[ky][1][e + 1];
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[ky * 3 + 2], 0, 0, 0);
+                    if constexpr (j < 7) {          // one read of the next group after every third of a k-step's MFMAs
+                        if (e == ky) nwin[ky] = bp[ky * XCH + j + 3];
+                        if (e == 3 && ky == 0) nav = ap[j + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bacc += a;
+            }
+            if constexpr (j < 7) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    win[ky][0] = win[ky][1];
+                    win[ky][1] = win[ky][2];
+                    win[ky][2] = nwin[ky];
+                }
+                av = nav;
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next strip's tiles have landed (this wave's part)
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    {
+        const float tot = bacc + __shfl_xor(bacc, 32, 64);
+        const int co = co0 + mt * 32 + l31;
+        if (p.bpart && blockIdx.z == 0 && cit == 0 && kh == 0 && co < p.Cout) p.bpart[(int64_t)blockIdx.x * p.Cout + co] = tot;
+    }
+    const int ci = ci0 + cit * 32 + l31;
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.Cin * 9;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + mt * 32 + acc_row(r, kh);
+            if (co < p.Cout) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) out[((int64_t)co * p.Cin + ci) * 9 + i] = acc[i][r];
+            }
+        }
+    }
+}
+
+int g_wgrad_rows = 1;      // 3x3: the LDS-DMA / row-paired form when the image rows are 16-byte aligned (0: always the first form)
+
 int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
     const int64_t strips = (int64_t)B * ((H + 1) / 2) * ((W + 31) / 32);
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
@@ -375,7 +537,18 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
-    if (ks == 3) {
+    const bool rows_form = ks == 3 && g_wgrad_rows && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) &&
+                           cwfa_aligned16(dy) && (int64_t)H * W % 4 == 0;
+    if (rows_form) {
+        static bool attr_r = false;
+        if (!attr_r) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, wr::LDS_BYTES);
+            CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_r = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_rows_kernel, grid, dim3(256), wr::LDS_BYTES, st, p);
+    } else if (ks == 3) {
         if (!attr3) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, 3>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<3, 3>::LDS_BYTES);

@@ -25,7 +25,9 @@ def _need_gpu():
 @pytest.mark.parametrize("cfg", [  # (B, Cin, Cout, H, W, ks)
     (1, 64, 64, 64, 64, 3), (2, 64, 64, 37, 45, 3), (1, 58, 64, 33, 31, 1), (2, 64, 24, 20, 70, 3), (1, 96, 96, 17, 33, 3),
     (1, 64, 64, 40, 40, 1), (3, 7, 5, 9, 11, 3), (1, 130, 70, 8, 8, 1), (1, 64, 64, 1, 1, 3), (1, 64, 64, 128, 128, 3),
-    (1, 64, 64, 37, 45, 7), (2, 6, 70, 12, 66, 7)])
+    (1, 64, 64, 37, 45, 7), (2, 6, 70, 12, 66, 7),
+    # W % 4 == 0: the LDS-DMA / row-paired form of the 3x3 kernel (ragged right edge, odd heights, partial channel tiles)
+    (2, 64, 64, 37, 44, 3), (1, 70, 130, 19, 36, 3), (1, 8, 8, 6, 4, 3), (1, 64, 64, 5, 100, 3), (3, 29, 48, 16, 32, 3)])
 def test_conv_weight_gradient_vs_autograd(cfg):
     from cwfa_amd import ops
     B, Cin, Cout, H, W, ks = cfg
