@@ -1590,6 +1590,10 @@ extern "C" int cwfa_set_option(const char* name, int value) {
         g_cwfa_wino_2d = value;
         return CWFA_OK;
     }
+    if (strcmp(name, "wgrad_rows") == 0) {          // 0: the 3x3 weight gradient always takes its first (register-staged) form
+        g_cwfa_wgrad_rows = value;
+        return CWFA_OK;
+    }
     if (strcmp(name, "split_products") == 0) {      // 6: fp32-accurate split; 1: plain bf16 operands (BASELINE configs[4])
         CWFA_REQUIRE(value == 1 || value == 6, CWFA_E_INVAL, "cwfa_set_option: split_products must be 1 or 6");
         g_cwfa_split_products = value;

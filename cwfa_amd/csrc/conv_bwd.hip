@@ -444,7 +444,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(WgParams p) {
     }
 }
 
-int g_wgrad_rows = 1;      // 3x3: the LDS-DMA / row-paired form when the image rows are 16-byte aligned (0: always the first form)
+}  // namespace
+int g_cwfa_wgrad_rows = 1;   // 3x3: the LDS-DMA / row-paired form when the image rows are 16-byte aligned (option "wgrad_rows")
+namespace {
 
 int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
     const int64_t strips = (int64_t)B * ((H + 1) / 2) * ((W + 31) / 32);
@@ -537,7 +539,7 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
-    const bool rows_form = ks == 3 && g_wgrad_rows && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) &&
+    const bool rows_form = ks == 3 && g_cwfa_wgrad_rows && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) &&
                            cwfa_aligned16(dy) && (int64_t)H * W % 4 == 0;
     if (rows_form) {
         static bool attr_r = false;

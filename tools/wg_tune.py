@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {"base": [], "nostage": ["-DCWFA_EXP_WG_NOSTAGE"], "nomfma": ["-DCWFA_EXP_WG_NOMFMA"],
             "nostage_nolds": ["-DCWFA_EXP_WG_NOSTAGE", "-DCWFA_EXP_WG_NOLDS"],
-            "burst": ["-DCWFA_EXP_WG_BURST"]}
+            "burst": ["-DCWFA_EXP_WG_BURST"], "rows": []}
 
 
 def build():
@@ -35,6 +35,8 @@ def run_one(name):
     from cwfa_amd import _lib
     _lib.LIB_PATH = os.path.join(VDIR, f"libwg_{name}.so")
     from cwfa_amd import ops
+    if name != "rows":
+        ops.set_option("wgrad_rows", 0)             # the knobs below belong to the first (register-staged) form
     x = torch.randn(1, 64, 512, 512, device="cuda")
     dy = torch.randn(1, 64, 512, 512, device="cuda")
     for _ in range(3):
