@@ -57,6 +57,7 @@ SIGNATURES = {
     "cwfa_conv2d_pack_f32": (i, [p, p, i, i, i, i, p]),
     "cwfa_conv2d_f32": (i, [p, p, p, i, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
     "cwfa_subnet_pack1x1_f32": (i, [p, p, p]),
+    "cwfa_subnet_layer_tape_f32": (i, [p, p, p, p, p, p, p, i, i, i, i64, i64, i64, p]),
     "cwfa_subnet_layer_f32": (i, [p, p, p, p, p, p, i, i, i, i64, i64, p]),
     "cwfa_conv3d_1k1_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
     "cwfa_channel_stats_f32": (i, [p, p, i, i, i64, i64, p]),

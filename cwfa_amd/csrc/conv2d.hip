@@ -1668,6 +1668,22 @@ extern "C" int cwfa_subnet_pack1x1_f32(const float* w, float* panel, void* strea
     return CWFA_OK;
 }
 
+extern "C" int cwfa_subnet_layer_tape_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel,
+                                          const float* b1, float* y, float* hidden, int B, int H, int W, int64_t x_bs, int64_t y_bs,
+                                          int64_t hidden_bs, void* stream) {
+    ConvParams p{};
+    cwfa_conv_opts o{};
+    o.bias = b3;
+    int rc = fill_params(p, "cwfa_subnet_layer_tape_f32", x, w3_packed, y, B, 64, H, W, 64, x_bs, y_bs, &o);
+    if (rc) return rc < 0 ? rc : CWFA_OK;
+    CWFA_REQUIRE(b3 && w1_panel && b1 && hidden, CWFA_E_INVAL, "cwfa_subnet_layer_tape_f32: null pointer");
+    CWFA_REQUIRE(x != y && x != hidden && y != hidden, CWFA_E_INVAL, "cwfa_subnet_layer_tape_f32: x, y and hidden must be distinct");
+    CWFA_REQUIRE(cwfa_aligned16(w1_panel), CWFA_E_ALIGN, "cwfa_subnet_layer_tape_f32: 1x1 panel must be 16-byte aligned");
+    CWFA_REQUIRE(cwfa_wino_selected(3, 64), CWFA_E_INVAL,
+                 "cwfa_subnet_layer_tape_f32: needs the Winograd packing of the 3x3 bank (option winograd_min_cout <= 64)");
+    return cwfa_wino_layer(x, w3_packed, b3, w1_panel, b1, y, B, H, W, x_bs, y_bs, (hipStream_t)stream, hidden, hidden_bs);
+}
+
 extern "C" int cwfa_subnet_layer_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel,
                                      const float* b1, float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream) {
     ConvParams p{};

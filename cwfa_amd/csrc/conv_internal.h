@@ -24,4 +24,5 @@ int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int C
                    int64_t y_bs, const cwfa_conv_opts& o, hipStream_t stream);
 // fused sub-network layer, 64 channels: y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x)
 int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1, float* y,
-                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream);
+                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream, float* hidden = nullptr,
+                    int64_t hidden_bs = 0);

@@ -68,6 +68,8 @@ struct WParams {
     cwfa_conv_opts o;
     const float* w1x1;
     const float* b1x1;
+    float* hidden;          // fused layer, training: the hidden map ELU(conv3x3 + b3) is written here as well (NULL: not kept)
+    int64_t hidden_bs;
 };
 
 #ifdef CWFA_EXP_STAMP
@@ -496,6 +498,7 @@ __device__ __forceinline__ float ld1(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+template <bool TAPE>
 __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p) {
     typedef W64 C;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -513,6 +516,8 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
                      (((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.y)) & 7) == 0);
     const float* xb = p.x + (int64_t)t.b * p.x_bs;
     float* yb = p.y + (int64_t)t.b * p.y_bs;
+    float* hb = TAPE ? p.hidden + (int64_t)t.b * p.hidden_bs : nullptr;
+    const bool vech = TAPE && ok1 && ((HW | p.W | p.hidden_bs) & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.hidden) & 7) == 0);
     const unsigned HW4 = (unsigned)HW * 4u;
     // per-lane byte offset of this lane's pixel pair in channel 4*kh; channel K adds the scalar K*HW4
     const unsigned oo = (ok0 ? (unsigned)(row * p.W + col) * 4u : 0u) + (unsigned)t.kh * 4u * HW4;
@@ -559,6 +564,12 @@ __global__ __launch_bounds__(W64::NTHREADS, 1) void wino_layer_kernel(WParams p)
                 if (j + 1 < 32) a_next = wl[((j + 1) * 2 + mo) * 64];
                 if (q == 0) acc[m][0][r] = cwfa_elu(((acc[m][0][r] + acc[m][1][r]) + acc[m][2][r]) + b3v[m][r]);
                 if (q == 1) acc[m][1][r] = cwfa_elu(((acc[m][1][r] - acc[m][2][r]) - acc[m][3][r]) + b3v[m][r]);
+                if constexpr (TAPE) {
+                    if (q == 1) {                           // both pixels of hidden channel m*32 + row(r) are final: keep them
+                        const f32x2 hv = {acc[m][0][r], acc[m][1][r]};
+                        if (ok0) st2(hb, (unsigned)(m * 32 + acc_row(r, 0)) * HW4 + oo, hv, vech, ok0, ok1);
+                    }
+                }
                 if (j == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][par][r], zero, 0, 0, 0);
@@ -687,7 +698,7 @@ int cwfa_wino_conv(const float* x, const float* w_packed, float* y, int B, int C
 }
 
 int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1, float* y,
-                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream) {
+                    int B, int H, int W, int64_t x_bs, int64_t y_bs, hipStream_t stream, float* hidden, int64_t hidden_bs) {
     typedef W64 C;
     WParams p{};
     p.x = x; p.wp = w3_packed; p.y = y;
@@ -696,6 +707,8 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
     p.o.bias = b3;
     p.w1x1 = w1_panel;
     p.b1x1 = b1;
+    p.hidden = hidden;
+    p.hidden_bs = hidden_bs;
     p.tiles_x = (W + C::TCOLS - 1) / C::TCOLS;
     p.tiles_y = (H + C::TR - 1) / C::TR;
     p.nchunks = 64 / C::CK;
@@ -704,8 +717,11 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
                  "cwfa_subnet_layer_f32: one sample's input must stay below 2 GiB (32-bit buffer offsets)");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_layer_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_layer_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_layer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
         if (e != hipSuccess) {
             cwfa_set_error("cwfa_subnet_layer_f32: hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
             return CWFA_E_HIP;
@@ -713,7 +729,10 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
         attr_set = true;
     }
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), 1, B);
-    hipLaunchKernelGGL(wino_layer_kernel, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    if (hidden)
+        hipLaunchKernelGGL(wino_layer_kernel<true>, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL(wino_layer_kernel<false>, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_f32 (winograd)");
     return CWFA_OK;
 }

@@ -407,14 +407,22 @@ def pack_split_layer_weight(w):
     return PackedConv(packed, 64, 64, 3, False, w._version, w.data_ptr(), split=True)
 
 
-def subnet_layer(x, pc3, b3, panel1, b1):
-    """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch."""
+def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False):
+    """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch.  ``want_hidden`` (training forward):
+    returns (y, h) with h = ELU(conv3x3(x) + b3), written by the same launch."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
     if Cc != 64 or pc3.cin != 64 or pc3.cout != 64 or pc3.ks != 3:
         raise ValueError("subnet_layer: 64-channel 3x3 layers only")
     out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+    if want_hidden:
+        if pc3.split:
+            raise ValueError("subnet_layer: the tape form runs on the fp32 Winograd layer kernel")
+        hid = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+        check(L.cwfa_subnet_layer_tape_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), _p(hid), B, H, W,
+                                           xbs, 64 * H * W, 64 * H * W, _stream()), "subnet_layer_tape")
+        return out, hid
     if pc3.split:
         check(L.cwfa_subnet_layer_split_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
                                             xbs, 64 * H * W, _stream()), "subnet_layer_split")

@@ -192,6 +192,11 @@ int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int 
 int cwfa_subnet_pack1x1_f32(const float* w, float* panel, void* stream);
 int cwfa_subnet_layer_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1,
                           float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream);
+/* The same layer for the training forward: additionally writes the hidden map h = ELU(conv3x3(x) + b3) [B,64,H,W] (batch
+ * stride hidden_bs) that the backward needs, from the accumulators it already holds (one extra store per element). */
+int cwfa_subnet_layer_tape_f32(const float* x, const float* w3_packed, const float* b3, const float* w1_panel, const float* b1,
+                               float* y, float* hidden, int B, int H, int W, int64_t x_bs, int64_t y_bs, int64_t hidden_bs,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Condition-net 3-D part:  Conv3d(1->K,3^3,pad 1) -> PReLU -> Conv3d(K->1,3^3,pad 1), fused
