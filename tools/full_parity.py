@@ -25,3 +25,13 @@ with torch.no_grad():
     ref = O.inverse_pass(steps, None, ci, mc, lrnn_sd=cpu(enc.state_dict()), lrnn_train=True)[-1]
 d = (out - ref)
 print(f"full-size config-3 inverse: max|d|/max|ref| = {float(d.abs().max() / ref.abs().max()):.3e}, L2-rel = {float(d.norm() / ref.norm()):.3e}")
+from cwfa_amd import ops
+for mode in ("split_bf16", "bf16"):
+    ops.set_precision(mode)
+    try:
+        with torch.no_grad():
+            o2 = CWFA.inverse_pass(conv_inn, cond_nets, ci.cuda(), [m.cuda() for m in mc]).cpu()
+    finally:
+        ops.set_precision("fp32")
+    d2 = o2 - ref
+    print(f"  precision mode {mode}: max|d|/max|ref| = {float(d2.abs().max() / ref.abs().max()):.3e}, L2-rel = {float(d2.norm() / ref.norm()):.3e}")
