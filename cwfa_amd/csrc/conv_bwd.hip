@@ -703,6 +703,56 @@ __global__ __launch_bounds__(256) void conv3d_input_bwd_kernel(const float* __re
     dx[(int64_t)b * vol + i] = acc;
 }
 
+// The same for images whose rows are 16-byte aligned (W % 4 == 0): a thread owns FOUR consecutive voxels along x, so a
+// (depth, row) line of the stencil is six values -- one 4-byte, one 16-byte and one 4-byte load -- feeding 12 FMAs:
+// 27 load instructions per hidden channel and four outputs instead of 108.
+__global__ __launch_bounds__(256) void conv3d_input_bwd4_kernel(const float* __restrict__ m, const float* __restrict__ w1,
+                                                                float* __restrict__ dx, int D, int H, int W, int K) {
+    const int64_t vol = (int64_t)D * H * W, q4 = vol / 4;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= q4) return;
+    const int b = blockIdx.y;
+    const int64_t i = i4 * 4;
+    const int x0 = (int)(i % W), y = (int)((i / W) % H), d = (int)(i / ((int64_t)H * W));
+    constexpr unsigned OOB = 0x80000000u;
+    // line (id, ih): source line (d - (id-1), y - (ih-1)); byte offsets of its three pieces, or the out-of-range marker
+    unsigned ol[9], om[9], orr[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+        const int ih = l / 3, id = l % 3;
+        const int sy = y - (ih - 1), sd = d - (id - 1);
+        const bool ok = sy >= 0 && sy < H && sd >= 0 && sd < D;
+        const unsigned base = (unsigned)((((int64_t)sd * H + sy) * W + x0) * 4);
+        om[l] = ok ? base : OOB;
+        ol[l] = ok && x0 > 0 ? base - 4u : OOB;
+        orr[l] = ok && x0 + 4 < W ? base + 16u : OOB;
+    }
+    const auto rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m + (int64_t)b * K * vol), 0, (int)((int64_t)K * vol * 4),
+                                                      0x00020000);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const int so = (int)((int64_t)k * vol * 4);
+        const float* wk = w1 + k * 27;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            const int ih = l / 3, id = l % 3;
+            float v[6];
+            v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, ol[l], so, 0));
+            const f32x4 mid = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, om[l], so, 0));
+            v[1] = mid[0]; v[2] = mid[1]; v[3] = mid[2]; v[4] = mid[3];
+            v[5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, orr[l], so, 0));
+            // dx[x0 + j] += W1[k][ih][iw][id] * m[x0 + j - (iw - 1)]  ->  v index j + 1 - (iw - 1) = j + 2 - iw
+#pragma unroll
+            for (int iw = 0; iw < 3; ++iw) {
+                const float wv = wk[(ih * 3 + iw) * 3 + id];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, v[j + 2 - iw], acc[j]);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(dx + (int64_t)b * vol + i) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+}
+
 // GEMM over voxels on the matrix cores: D[k][tap] += A[k][p] * src[p + sign*(tap - 1)];  column 27 multiplies ones (the
 // bias gradient of the convolution whose output gradient is A).  A wave owns runs of 64 voxels along x (32 k-steps of two
 // voxels); lane (l31, kh) feeds row k = l31 of A and column tap = l31 of the shifted source, both straight from global
@@ -813,8 +863,12 @@ extern "C" int cwfa_conv3d_input_bwd_f32(const float* m, const float* w1, float*
     if (rc) return rc;
     if (B == 0) return CWFA_OK;
     const int64_t vol = (int64_t)D * H * W;
-    hipLaunchKernelGGL(conv3d_input_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, m, w1, dx, D,
-                       H, W, K);
+    if (W % 4 == 0 && cwfa_aligned16(m) && cwfa_aligned16(dx))
+        hipLaunchKernelGGL(conv3d_input_bwd4_kernel, dim3((unsigned)((vol / 4 + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, m, w1,
+                           dx, D, H, W, K);
+    else
+        hipLaunchKernelGGL(conv3d_input_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, m, w1, dx,
+                           D, H, W, K);
     CWFA_LAUNCH_CHECK("cwfa_conv3d_input_bwd_f32");
     return CWFA_OK;
 }

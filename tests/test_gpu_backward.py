@@ -259,7 +259,8 @@ def test_full_training_loss_backward_golden(name, kind):
     assert_close(out["cond_grads"][1], fx[f"full_{kind}/gc1"], TOL if kind == "l2" else 5e-4, "d loss / d mean detail")
 
 
-@pytest.mark.parametrize("cfg", [(2, 6, 9, 11, 5), (1, 12, 20, 70, 32), (1, 3, 5, 130, 8), (3, 1, 4, 4, 2)])   # (B, D, H, W, K)
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 11, 5), (1, 12, 20, 70, 32), (1, 3, 5, 130, 8), (3, 1, 4, 4, 2), (2, 5, 7, 36, 9),
+                                 (1, 8, 16, 64, 32)])   # (B, D, H, W, K); W % 4 == 0 takes the four-voxel input-gradient kernel
 def test_conv3d_stage_backward_vs_autograd(cfg):
     """Conv3d(1->K) -> PReLU -> Conv3d(K->1) over (H, W, depth) (networks.py:221-225,239): every gradient against float64
     autograd -- input, both filter banks, both biases, the PReLU slope."""
