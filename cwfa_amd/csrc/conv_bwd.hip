@@ -801,6 +801,68 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) out[acc_row(r, kh) * 32 + l31] = acc[r];
 }
 
+// The same GEMM for 16-byte aligned rows (W % 4 == 0): the MFMA k index pairs the two HALVES of a 64-voxel run (lane half
+// kh walks voxels x0 + 32 kh + s), so a lane's operands of consecutive k-steps are consecutive words -- one 16-byte load of
+// A per four k-steps, and for the shifted source the aligned chunk plus its neighbour in the lane's shift direction (the
+// four operands are picked with selects): 3 load instructions per four k-steps instead of 8.
+__global__ __launch_bounds__(256) void conv3d_wgrad4_kernel(const float* __restrict__ a, const float* __restrict__ src,
+                                                            const float* __restrict__ alpha_p, float* __restrict__ part, int B, int D,
+                                                            int H, int W, int K, int sign, int want_bias) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int64_t HW = (int64_t)H * W, vol = (int64_t)D * HW;
+    const int chunks = (W + 63) / 64;
+    const int64_t items = (int64_t)B * D * H * chunks;
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const int ih = l31 / 9, iw = (l31 / 3) % 3, id = l31 % 3;
+    const int sxo = sign * (iw - 1);                       // this lane's shift along x: -1, 0, +1
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t it = wave; it < items; it += nwaves) {
+        const int ch = (int)(it % chunks);
+        const int64_t row = it / chunks;
+        const int y = (int)(row % H), d = (int)((row / H) % D), b = (int)(row / ((int64_t)H * D));
+        const int xb = ch * 64 + 32 * kh;                   // first voxel of this lane's half-run
+        const float* ap = a + ((int64_t)b * K + l31) * vol + (int64_t)d * HW + (int64_t)y * W;
+        const int sy = y + sign * (ih - 1), sd = d + sign * (id - 1);
+        const bool row_ok = l31 < 27 && sy >= 0 && sy < H && sd >= 0 && sd < D;
+        const float* sp = src + (int64_t)b * vol + (int64_t)(row_ok ? sd : 0) * HW + (int64_t)(row_ok ? sy : 0) * W;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int x = xb + 4 * g;                       // voxels x .. x+3 are this group's four k-steps
+            f32x4 av = zero4, cur = zero4, nb = zero4;
+            if (x < W) {                                    // W % 4 == 0: a chunk is inside or outside as a whole
+                if (l31 < K) {
+                    av = *reinterpret_cast<const f32x4*>(ap + x);
+                    if (alpha_p) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = av[e] > 0.f ? av[e] : alpha * av[e];
+                    }
+                }
+                if (row_ok) {
+                    cur = *reinterpret_cast<const f32x4*>(sp + x);
+                    const int xn = x + 4 * sxo;              // the neighbouring chunk in the shift direction
+                    if (sxo != 0 && xn >= 0 && xn < W) nb = *reinterpret_cast<const f32x4*>(sp + xn);
+                }
+            }
+            // source voxel x + e + sxo
+            f32x4 bv;
+            bv[0] = sxo < 0 ? nb[3] : sxo > 0 ? cur[1] : cur[0];
+            bv[1] = sxo < 0 ? cur[0] : sxo > 0 ? cur[2] : cur[1];
+            bv[2] = sxo < 0 ? cur[1] : sxo > 0 ? cur[3] : cur[2];
+            bv[3] = sxo < 0 ? cur[2] : sxo > 0 ? nb[0] : cur[3];
+            if (l31 == 27 && want_bias && x < W) bv = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+    }
+    float* out = part + (int64_t)wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[acc_row(r, kh) * 32 + l31] = acc[r];
+}
+
 // PReLU backward from the layer's OUTPUT o = PReLU(q), single alpha > 0:  y = g * (o > 0 ? 1 : alpha),
 // dalpha += sum g * min(q, 0) with q = o / alpha where o < 0
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ o,
@@ -899,8 +961,12 @@ extern "C" int cwfa_conv3d_wgrad_f32(const float* a, const float* src, const flo
     if (B > 0) {
         const int blocks = c3_wgrad_blocks(B, D, H, W);
         nparts = blocks * 4;
-        hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(blocks), dim3(256), 0, st, a, src, alpha, reinterpret_cast<float*>(workspace), B, D,
-                           H, W, K, sign, want_bias);
+        if (W % 4 == 0 && cwfa_aligned16(a) && cwfa_aligned16(src))
+            hipLaunchKernelGGL(conv3d_wgrad4_kernel, dim3(blocks), dim3(256), 0, st, a, src, alpha, reinterpret_cast<float*>(workspace), B,
+                               D, H, W, K, sign, want_bias);
+        else
+            hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(blocks), dim3(256), 0, st, a, src, alpha, reinterpret_cast<float*>(workspace), B,
+                               D, H, W, K, sign, want_bias);
         CWFA_LAUNCH_CHECK("cwfa_conv3d_wgrad_f32");
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), out32, (int64_t)1024,
