@@ -1006,13 +1006,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
             float v = xv[k][j];
             if (has_aff) v = fok[k] ? v * aff[(ch0 + j) & 2047] + aff[2048 + ((ch0 + j) & 2047)] : 0.f;     // padding stays zero
             if constexpr (ADD) v += av[k][j];
-            unsigned short o[3];
-            split3(v, o);
+            unsigned short o[3] = {0, 0, 0};
+            if (six) split3(v, o);
+            else o[0] = __builtin_bit_cast(unsigned short, (__bf16)v);      // plain bf16 operands: the residual pieces are never read
             pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
         }
         if (fin[k]) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                if (q > 0 && !six) continue;
                 uint4 u;
                 u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
                 u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
@@ -1201,13 +1203,15 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
         unsigned short pc[3][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            unsigned short o[3];
-            split3(xv[k][j], o);
+            unsigned short o[3] = {0, 0, 0};
+            if (six) split3(xv[k][j], o);
+            else o[0] = __builtin_bit_cast(unsigned short, (__bf16)xv[k][j]);
             pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
         }
         if (fin[k]) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                if (q > 0 && !six) continue;
                 uint4 u;
                 u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
                 u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
