@@ -680,6 +680,71 @@ __global__ __launch_bounds__(256) void conv3d_hidden_bwd_kernel(const float* __r
     }
 }
 
+// Four voxels per thread for aligned rows (W % 4 == 0): a (depth, row) line of the stencil is one 4-byte, one 16-byte and one
+// 4-byte load, and every hidden-channel value moves as a 16-byte word.  SIGN +1: q = W1 * x + b1;  SIGN -1: m = (W2^T * dy).PReLU'(q).
+template <int SIGN>
+__global__ __launch_bounds__(256) void conv3d_hidden4_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ b1, const float* __restrict__ q,
+                                                             const float* __restrict__ alpha_p, float* __restrict__ out,
+                                                             double* __restrict__ dalpha, int D, int H, int W, int K) {
+    __shared__ double red[16];
+    const int64_t vol = (int64_t)D * H * W, q4 = vol / 4;
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    double da = 0.0;
+    if (i4 < q4) {
+        const int64_t i = i4 * 4;
+        const int x0 = (int)(i % W), y = (int)((i / W) % H), d = (int)(i / ((int64_t)H * W));
+        const float* ib = in + (int64_t)b * vol;
+        float v[9][6];                               // line (ih, id): voxels x0-1 .. x0+4 of row y + SIGN (ih-1), depth d + SIGN (id-1)
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+            const int ih = l / 3, id = l % 3;
+            const int sy = y + SIGN * (ih - 1), sd = d + SIGN * (id - 1);
+            const bool ok = sy >= 0 && sy < H && sd >= 0 && sd < D;
+            const float* lp = ib + ((int64_t)(ok ? sd : 0) * H + (ok ? sy : 0)) * W + x0;
+            const f32x4 mid = ok ? *reinterpret_cast<const f32x4*>(lp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[l][0] = ok && x0 > 0 ? lp[-1] : 0.f;
+            v[l][1] = mid[0]; v[l][2] = mid[1]; v[l][3] = mid[2]; v[l][4] = mid[3];
+            v[l][5] = ok && x0 + 4 < W ? lp[4] : 0.f;
+        }
+        const float alpha = SIGN < 0 ? *alpha_p : 0.f;
+        for (int k = 0; k < K; ++k) {
+            float acc[4];
+            const float bias = SIGN > 0 ? b1[k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = bias;
+#pragma unroll
+            for (int l = 0; l < 9; ++l)
+#pragma unroll
+                for (int iw = 0; iw < 3; ++iw) {
+                    const float wv = w[k * 27 + ((l / 3) * 3 + iw) * 3 + (l % 3)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, v[l][j + 1 + SIGN * (iw - 1)], acc[j]);
+                }
+            const int64_t o = ((int64_t)b * K + k) * vol + i;
+            if constexpr (SIGN > 0) {
+                *reinterpret_cast<f32x4*>(out + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(q + o);
+                f32x4 mv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mv[j] = qv[j] > 0.f ? acc[j] : alpha * acc[j];
+                    da += qv[j] > 0.f ? 0.0 : (double)acc[j] * (double)qv[j];
+                }
+                *reinterpret_cast<f32x4*>(out + o) = mv;
+            }
+        }
+    }
+    if constexpr (SIGN < 0) {
+        if (dalpha) {
+            const double tot = cwfa_block_sum(da, red);
+            if (threadIdx.x == 0) atomicAdd(dalpha, tot);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv3d_input_bwd_kernel(const float* __restrict__ m, const float* __restrict__ w1,
                                                                float* __restrict__ dx, int D, int H, int W, int K) {
     const int64_t vol = (int64_t)D * H * W;
@@ -900,8 +965,12 @@ extern "C" int cwfa_conv3d_hidden_fwd_f32(const float* x, const float* w1, const
     if (rc) return rc;
     if (B == 0) return CWFA_OK;
     const int64_t vol = (int64_t)D * H * W;
-    hipLaunchKernelGGL(conv3d_hidden_fwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, w1, b1, q,
-                       D, H, W, K);
+    if (W % 4 == 0 && cwfa_aligned16(x) && cwfa_aligned16(q))
+        hipLaunchKernelGGL(conv3d_hidden4_kernel<1>, dim3((unsigned)((vol / 4 + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, w1, b1,
+                           (const float*)nullptr, (const float*)nullptr, q, (double*)nullptr, D, H, W, K);
+    else
+        hipLaunchKernelGGL(conv3d_hidden_fwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, w1, b1,
+                           q, D, H, W, K);
     CWFA_LAUNCH_CHECK("cwfa_conv3d_hidden_fwd_f32");
     return CWFA_OK;
 }
@@ -913,8 +982,12 @@ extern "C" int cwfa_conv3d_hidden_bwd_f32(const float* dy, const float* w2, cons
     if (rc) return rc;
     if (B == 0) return CWFA_OK;
     const int64_t vol = (int64_t)D * H * W;
-    hipLaunchKernelGGL(conv3d_hidden_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, dy, w2, q,
-                       alpha, m, dalpha, D, H, W, K);
+    if (W % 4 == 0 && cwfa_aligned16(dy) && cwfa_aligned16(q) && cwfa_aligned16(m))
+        hipLaunchKernelGGL(conv3d_hidden4_kernel<-1>, dim3((unsigned)((vol / 4 + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, dy, w2,
+                           (const float*)nullptr, q, alpha, m, dalpha, D, H, W, K);
+    else
+        hipLaunchKernelGGL(conv3d_hidden_bwd_kernel, dim3((unsigned)((vol + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, dy, w2, q,
+                           alpha, m, dalpha, D, H, W, K);
     CWFA_LAUNCH_CHECK("cwfa_conv3d_hidden_bwd_f32");
     return CWFA_OK;
 }
