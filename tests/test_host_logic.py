@@ -152,3 +152,22 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     for (k, a), (_, b) in zip(inns[0].state_dict().items(), inns2[0].state_dict().items()):
         assert torch.equal(a, b), k
     assert ck["training_statistics"] == stats and ck["optimizer_state_dict"] is None
+
+
+def test_training_host_helpers_without_a_process_group():
+    """Host-side pieces of the training path that need neither a GPU nor torch.distributed."""
+    import torch
+    from cwfa_amd import CWFA, ops, training
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.tensor([1.0, 2.0, 3.0])
+    assert training.allreduce_gradients([p]) == 0                  # no process group: nothing to exchange
+    training.sgd_step([p], 0.5)
+    assert torch.equal(p.detach(), torch.tensor([0.5, 0.0, -0.5]))
+    scores = torch.tensor([[-1.0, -2.0], [-1.5, -0.5]], dtype=torch.float64)
+    assert CWFA.allgather_scores(scores) is scores
+    assert CWFA.detect_ood(scores, 0, -1.33).tolist() == [False, True]
+    assert CWFA.detect_ood(scores, 1, -1.33).tolist() == [True, False]
+    with pytest.raises(ValueError):
+        ops.set_precision("fp8")
+    with pytest.raises(NotImplementedError):
+        training.step_backward(type("G", (), {"_plan": None})(), None, [])
