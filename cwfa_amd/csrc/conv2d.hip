@@ -1154,265 +1154,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
     epilogue<C, EPI>(p, t, acc);
 }
 
-// ---- fused sub-network layer on the split-bf16 3x3 core (EXPERIMENTAL, with the split option at level 2)
-//   y = ELU( W1x1 . ELU( conv3x3(x) + b3 ) + b1 + x ), 64 channels (networks.py:624-631,660-665).
-// Block = 64 ch x 32 rows x 32 px, 8 waves of 2 x 4 accumulator tiles (one 4-row band each).  The 3x3 runs as in
-// conv3x3_split_kernel (fused mode) but with ONE input buffer -- a 16-channel chunk of the haloed tile is
-// [3 pieces][2 k halves][34 rows][34 px] x 16 B = 111 KB -- so the next chunk waits in registers (5 entries per thread,
-// loaded during the first five taps) and is split and stored between two barriers at the chunk boundary (4 per tile).
-// Weights: 6 KB per tap-step through a three-buffer LDS-DMA ring.  The 1x1 stays on the fp32 matrix cores: the 3x3
-// accumulators are its B operand register by register, exactly as in subnet_layer_kernel above (eight passes of 32
-// chained MFMAs; bias, residual, ELU and the store of pass q-1 are slotted under the MFMAs of pass q).
-typedef Cfg<1, 16, 2, 4, 1, 8> CSL;
-constexpr int SL_XE = 2 * 34 * 34, SL_XPB = SL_XE * 16, SL_XB = 3 * SL_XPB, SL_WB = 3 * 2 * 64 * 16, SL_LDS = SL_XB + 3 * SL_WB + 2048;
-
-__global__ __launch_bounds__(512, 1) void split_layer_kernel(ConvParams p) {
-    typedef CSL C;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);                   // [input tile SL_XB][3 x SL_WB weight slices]
-    const Tile t = make_tile<C>(p);
-    const bool six = p.products != 1;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int64_t HW = (int64_t)p.H * p.W;
-    constexpr unsigned OOB = 0x80000000u;
-
-    // staging entries e = tid + k*512 < 2312 of the [k half][34 rows][34 px] tile
-    unsigned fo[5];
-    bool fin[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int e = tid + k * 512;
-        const int c = e % 34, r = (e / 34) % 34, h = e / 1156;
-        const int gr = t.row0 + r - 1, gc = t.col0 + c - 1;
-        fin[k] = e < SL_XE;
-        fo[k] = (fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W) ? (unsigned)(((int64_t)h * 8 * HW + (int64_t)gr * p.W + gc) * 4) : OOB;
-    }
-    const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, (int)(64 * HW * 4), 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 4 * 9 * SL_WB, 0x00020000);
-    const int plane = (int)(HW * 4);
-    float xv[5][8];
-    auto load_entry = [&](auto kc, int chunk) {
-        constexpr int k = decltype(kc)::value;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            xv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, fo[k], (chunk * 16 + j) * plane, 0));
-    };
-    auto store_entry = [&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const int e = tid + k * 512;
-        unsigned short pc[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned short o[3] = {0, 0, 0};
-            if (six) split3(xv[k][j], o);
-            else o[0] = __builtin_bit_cast(unsigned short, (__bf16)xv[k][j]);
-            pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
-        }
-        if (fin[k]) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (q > 0 && !six) continue;
-                uint4 u;
-                u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
-                u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
-                u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
-                u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
-                *reinterpret_cast<uint4*>(lds + q * SL_XPB + e * 16) = u;
-            }
-        }
-    };
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    // 384 entries of 16 B per slice: waves 0..5 carry it; waves 6, 7 issue the same instruction into a 2 KB dump area past the
-    // ring with an out-of-range offset (zeros), so that the step has no branch in it
-    const int dma_dst = wave < 6 ? wave * 1024 : 3 * SL_WB + (wave - 6) * 1024 - SL_WB * 0;
-    const unsigned dma_off = wave < 6 ? (unsigned)tid * 16u : OOB;
-    auto dma_w = [&](int step, int wbuf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + SL_XB + (wave < 6 ? wbuf * SL_WB : 0) + dma_dst), 16, dma_off,
-                                                 step * SL_WB, 0, 0);
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    const char* alane = lds + SL_XB + (t.kh * 64 + t.l31) * 16;                                // + wbuf*SL_WB + (piece*128 + m*32)*16
-    const char* blane = lds + ((t.kh * 34 + t.wn * 4) * 34 + t.l31) * 16;                      // + piece*SL_XPB + ((n+dy)*34 + dx)*16
-
-    static_for<5>([&](auto kc) { load_entry(kc, 0); });
-    static_for<5>([&](auto kc) { store_entry(kc); });
-    dma_w(0, 0);
-    dma_w(1, 1);
-    asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int wbuf = 0, step = 0;
-    for (int chunk = 0; chunk < 4; ++chunk) {
-        static_for<9>([&](auto tc) {
-            constexpr int tap = decltype(tc)::value, dy = tap / 3, dx = tap % 3;
-            // All eight waves leave the barrier together and want 12 KB of operands each: issue the reads in the order the
-            // MFMAs consume them (the first needs two of the twelve), so the matrix pipe starts after 2 reads, not 12.
-            const char* ab = alane + wbuf * SL_WB;
-            bf16x8 A[2][3], Bq[2][3];
-            auto rdA = [&](int m, int q) { A[m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 128 + m * 32) * 16); };
-            auto rdB = [&](int n, int q) { Bq[n & 1][q] = *reinterpret_cast<const bf16x8*>(blane + q * SL_XPB + ((n + dy) * 34 + dx) * 16); };
-            rdA(0, 2); rdB(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            rdA(1, 2); rdA(0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            rdA(1, 1); rdA(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            rdA(1, 0); rdB(0, 1); rdB(0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            int nb = wbuf + 2;
-            nb = nb >= 3 ? nb - 3 : nb;
-            dma_w(step + 2, nb);
-            if constexpr (tap < 5) load_entry(sc_int<tap>{}, chunk + 1);        // past the last chunk: out of range, zeros, never stored
-            __builtin_amdgcn_sched_barrier(0);
-#define SL_MFMA(m, n, qa, qb)                                                                                             \
-    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][qa], Bq[(n) & 1][qb], acc[m][n], 0, 0, 0);                    \
-    __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (six) {
-                    SL_MFMA(0, n, 2, 0); SL_MFMA(1, n, 2, 0); SL_MFMA(0, n, 1, 0); SL_MFMA(1, n, 1, 0);
-                }
-                SL_MFMA(0, n, 0, 0); SL_MFMA(1, n, 0, 0);
-                if (six) {
-                    SL_MFMA(0, n, 1, 1); SL_MFMA(1, n, 1, 1); SL_MFMA(0, n, 0, 1); SL_MFMA(1, n, 0, 1);
-                }
-                if (n < 3) {                 // Bq[(n+1)&1] was last read by step-part n-1
-                    rdB(n + 1, 0); rdB(n + 1, 1); rdB(n + 1, 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (six) {
-                    SL_MFMA(0, n, 0, 2); SL_MFMA(1, n, 0, 2);
-                }
-            }
-#undef SL_MFMA
-            // weight slice step+1 (issued one step ago) has landed; this step's own loads (1 DMA, 8 input loads in the
-            // first five taps) may stay in flight
-            if constexpr (tap < 5) asm volatile("s_waitcnt vmcnt(9)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            wbuf = wbuf + 1 == 3 ? 0 : wbuf + 1;
-            ++step;
-        });
-#ifndef CWFA_EXP_SL_NOBOUNDARY
-        if (chunk < 3) {                                   // every wave is past its last read of this chunk's tile
-            static_for<5>([&](auto kc) { store_entry(kc); });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-#endif
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // zero-fill DMAs / loads past the end
-    __syncthreads();
-
-    // ---- 1x1 GEMM on the fp32 matrix cores + residual + ELU: subnet_layer_kernel's quarter passes, eight of them
-    const int col = t.col0 + t.l31;
-    const bool col_ok = col < p.W;
-    const float* xb = p.x + (int64_t)t.b * p.x_bs;
-    float* yb = p.y + (int64_t)t.b * p.y_bs;
-    unsigned oo[4];
-    bool ok[4];
-    const unsigned HW4 = (unsigned)HW * 4u;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int row = t.row0 + t.wn * 4 + n;
-        ok[n] = col_ok && row < p.H;
-        oo[n] = (ok[n] ? (unsigned)(row * p.W + col) * 4u : 0u) + (unsigned)t.kh * 4u * HW4;
-    }
-    auto load_res = [&](int mo, int n, f32x16& res) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned K = (unsigned)(mo * 32 + acc_row(r, 0));
-            res[r] = ldg_off(xb, K * HW4 + oo[n]) + ldg_off(p.b1x1, K * 4u + (unsigned)t.kh * 16u);
-        }
-    };
-    f32x16 yq[8], rq[8];
-    f32x16 b3v[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) b3v[m][r] = ldg_off(p.o.bias, (unsigned)(m * 32 + acc_row(r, 0)) * 4u + (unsigned)t.kh * 16u);
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.w1x1);
-        f32x4* dst = reinterpret_cast<f32x4*>(smem);
-        for (int e = threadIdx.x; e < 1024; e += C::NTHREADS) dst[e] = src[e];
-    }
-    __syncthreads();
-    const float* wl = smem + (threadIdx.x & 63);
-#ifdef CWFA_EXP_SL_SKIP1X1
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[n]) stg_off(yb, (unsigned)(m * 32 + acc_row(r, 0)) * HW4 + oo[n], cwfa_elu(acc[m][n][r] + b3v[m][r]));
-    return;
-#endif
-    // pass order n-major: both cout halves of one 4-row band back to back, so its 32 hidden registers die early
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int mo = q & 1, n = q >> 1;
-        load_res(mo, n, rq[q]);
-        float a_next = wl[(0 * 2 + mo) * 64];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = m * 16 + r;
-                const float a = a_next;
-                if (j + 1 < 32) a_next = wl[((j + 1) * 2 + mo) * 64];
-                if (mo == 0) acc[m][n][r] = cwfa_elu(acc[m][n][r] + b3v[m][r]);
-                if (j == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][n][r], zero, 0, 0, 0);
-                } else {
-                    yq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[m][n][r], yq[q], 0, 0, 0);
-                }
-                if (q > 0 && (j & 1)) {
-                    const int pq = q > 0 ? q - 1 : 0, pmo = pq & 1, pn = pq >> 1, rr = j >> 1;
-                    const unsigned K = (unsigned)(pmo * 32 + acc_row(rr, 0));
-                    if (ok[pn]) stg_off(yb, K * HW4 + oo[pn], cwfa_elu(yq[pq][rr] + rq[pq][rr]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {                            // tail: the last pass (mo = 1, n = 3)
-        const unsigned K = (unsigned)(32 + acc_row(r, 0));
-        if (ok[3]) stg_off(yb, K * HW4 + oo[3], cwfa_elu(yq[7][r] + rq[7][r]));
-    }
-}
-
-// the 64 x 64 x 3 x 3 bank of that layer: [chunk 4][tap 9][piece 3][k half 2][64 cout][8]
-__global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // over [chunk][tap][h][co]
-    if (i >= 4 * 9 * 128) return;
-    const int col = i % 64, h = (i / 64) % 2, tap = (i / 128) % 9, chunk = i / (128 * 9);
-    unsigned short pc[3][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        unsigned short o[3];
-        split3(w[((int64_t)col * 64 + chunk * 16 + h * 8 + j) * 9 + tap], o);
-        pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        uint4 u;
-        u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
-        u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
-        u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
-        u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
-        out[((chunk * 9 + tap) * 3 + q) * 128 + h * 64 + col] = u;
-    }
-}
-
 template <int EPI, int KS, int MODE = SPLIT_PRE>
 int launch_split(SplitParams sp, hipStream_t stream) {
     ConvParams& p = sp.c;
@@ -1539,46 +1280,6 @@ extern "C" int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed
         case EPI_PRELU: return launch_split<EPI_PRELU, 3, SPLIT_FUSED>(sp, st);
         default: return launch_split<EPI_GENERIC, 3, SPLIT_FUSED>(sp, st);
     }
-}
-
-extern "C" int cwfa_subnet_split_pack3x3_f32(const float* w, void* packed, void* stream) {
-    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_subnet_split_pack3x3_f32: null pointer");
-    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_split_pack3x3_f32: packed image must be 16-byte aligned");
-    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((4 * 9 * 128 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<uint4*>(packed));
-    CWFA_LAUNCH_CHECK("cwfa_subnet_split_pack3x3_f32");
-    return CWFA_OK;
-}
-
-extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* w3_split, const float* b3, const float* w1_panel,
-                                           const float* b1, float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream) {
-    ConvParams p{};
-    cwfa_conv_opts o{};
-    o.bias = b3;
-    int rc = fill_params(p, "cwfa_subnet_layer_split_f32", x, reinterpret_cast<const float*>(w3_split), y, B, 64, H, W, 64, x_bs, y_bs, &o);
-    if (rc) return rc < 0 ? rc : CWFA_OK;
-    CWFA_REQUIRE(b3 && w1_panel && b1, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: null pointer");
-    CWFA_REQUIRE(x != y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: in-place not supported (3x3 halo)");
-    CWFA_REQUIRE(cwfa_aligned16(w1_panel), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: 1x1 panel must be 16-byte aligned");
-    CWFA_REQUIRE((int64_t)96 * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "cwfa_subnet_layer_split_f32: image too large for 32-bit offsets");
-    p.w1x1 = w1_panel;
-    p.b1x1 = b1;
-    p.nchunks = 4;
-    p.tiles_x = (W + CSL::TC - 1) / CSL::TC;
-    p.tiles_y = (H + CSL::TR - 1) / CSL::TR;
-    CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_subnet_layer_split_f32: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&split_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
-        if (e != hipSuccess) {
-            cwfa_set_error("cwfa_subnet_layer_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", SL_LDS, hipGetErrorString(e));
-            return CWFA_E_HIP;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(split_layer_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y), 1, B), dim3(512), SL_LDS, (hipStream_t)stream, p);
-    CWFA_LAUNCH_CHECK("cwfa_subnet_layer_split_f32");
-    return CWFA_OK;
 }
 
 int g_cwfa_wino_min_cout = 1;

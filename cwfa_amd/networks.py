@@ -135,18 +135,21 @@ class wavelet_flow_subnetwork(nn.Module):
                                         for blk in (self.block2, self.block4, self.block6))
         for blk in (self.block2, self.block4, self.block6):
             if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
-                split = ops._split_bf16 >= 2 and 96 * b.shape[2] * b.shape[3] * 4 < 2 ** 31     # opt-in: 3x3 on the bf16 matrix pipe
-                b = ops.subnet_layer(b, self._split3(blk[0]) if split else P(blk[0]), blk[0].bias, self._panel(blk[2]), blk[2].bias)
+                if ops._split_bf16 >= 2 and 64 * b.shape[2] * b.shape[3] * 4 < 2 ** 31:   # both convs on the bf16 matrix pipe
+                    b = ops.subnet_layer(b, self._split3(blk[0], blk[2]), blk[0].bias, None, blk[2].bias)
+                else:
+                    b = ops.subnet_layer(b, P(blk[0]), blk[0].bias, self._panel(blk[2]), blk[2].bias)
                 continue
             h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")
             b = ops.conv2d(h, P(blk[2]), bias=blk[2].bias, residual=b, act2="elu")   # ELU = block3 / block5 / block7x[0]
         return ops.conv2d(b, P(conv_out), bias=conv_out.bias, out=out)
 
-    def _split3(self, conv):
-        w = conv.weight
-        pc = self._panels.get(("s", id(conv)))
-        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch():
-            pc = self._panels[("s", id(conv))] = ops.pack_split_layer_weight(w)
+    def _split3(self, conv3, conv1):
+        w, w1 = conv3.weight, conv1.weight
+        pc = self._panels.get(("s", id(conv3)))
+        if (pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.version1 != w1._version
+                or pc.src_ptr1 != w1.data_ptr() or pc.epoch != ops.pack_epoch()):
+            pc = self._panels[("s", id(conv3))] = ops.pack_split_layer_weight(w, w1)
         return pc
 
     def _panel(self, conv):

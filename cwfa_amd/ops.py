@@ -269,7 +269,7 @@ def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=Non
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
-    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch")
+    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch", "version1", "src_ptr1")
 
     def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
@@ -396,20 +396,24 @@ def pack_1x1_panel(w):
     return PackedConv(panel, 64, 64, 1, False, w._version, w.data_ptr())
 
 
-def pack_split_layer_weight(w):
-    """[64,64,3,3] filter -> the split-bf16 image of the experimental fused layer (set_option("split_bf16", 2))."""
+def pack_split_layer_weight(w3, w1):
+    """[64,64,3,3] and [64,64,1,1] filters -> the split-bf16 image of the fused layer (40 slices of three bf16 pieces)."""
     L = _lib.lib()
-    w = _dev(w, "weight").detach().contiguous()
-    if tuple(w.shape) != (64, 64, 3, 3):
-        raise ValueError("pack_split_layer_weight: 64x64x3x3 only")
-    packed = torch.empty(4 * 9 * 6144, dtype=torch.uint8, device=w.device)
-    check(L.cwfa_subnet_split_pack3x3_f32(_p(w), _p(packed), _stream()), "subnet_split_pack3x3")
-    return PackedConv(packed, 64, 64, 3, False, w._version, w.data_ptr(), split=True)
+    w3 = _dev(w3, "weight").detach().contiguous()
+    w1 = _dev(w1, "weight").detach().contiguous()
+    if tuple(w3.shape) != (64, 64, 3, 3) or tuple(w1.shape) != (64, 64, 1, 1):
+        raise ValueError("pack_split_layer_weight: 64x64x3x3 and 64x64x1x1 only")
+    packed = torch.empty(L.cwfa_subnet_layer_split_packed_bytes(), dtype=torch.uint8, device=w3.device)
+    check(L.cwfa_subnet_layer_split_pack_f32(_p(w3), _p(w1), _p(packed), _stream()), "subnet_layer_split_pack")
+    pc = PackedConv(packed, 64, 64, 3, False, w3._version, w3.data_ptr(), split=True)
+    pc.version1, pc.src_ptr1 = w1._version, w1.data_ptr()
+    return pc
 
 
 def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False):
     """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch.  ``want_hidden`` (training forward):
-    returns (y, h) with h = ELU(conv3x3(x) + b3), written by the same launch."""
+    returns (y, h) with h = ELU(conv3x3(x) + b3), written by the same launch.  With ``pc3`` from
+    pack_split_layer_weight (both banks in one split-bf16 image) ``panel1`` is unused."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
@@ -423,18 +427,18 @@ def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False):
         check(L.cwfa_subnet_layer_tape_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), _p(hid), B, H, W,
                                            xbs, 64 * H * W, 64 * H * W, _stream()), "subnet_layer_tape")
         return out, hid
-    if pc3.split:
-        check(L.cwfa_subnet_layer_split_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
-                                            xbs, 64 * H * W, _stream()), "subnet_layer_split")
-        return out
     rec = conv_event_sink
     if rec is not None:
-        key = ("L", 64, 64, H, W, B, "layer", False)
+        key = ("L", 64, 64, H, W, B, "layer+split" if pc3.split else "layer", False)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-    check(L.cwfa_subnet_layer_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
-                                  xbs, 64 * H * W, _stream()), "subnet_layer")
+    if pc3.split:
+        check(L.cwfa_subnet_layer_split_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), B, H, W,
+                                            xbs, 64 * H * W, _stream()), "subnet_layer_split")
+    else:
+        check(L.cwfa_subnet_layer_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
+                                      xbs, 64 * H * W, _stream()), "subnet_layer")
     if rec is not None and rec.want(key):
         e1.record()
         rec.add(key, e0, e1)

@@ -263,12 +263,15 @@ int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y,
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 
-/* EXPERIMENTAL: the fused sub-network layer (cwfa_subnet_layer_f32) with its 3x3 convolution on the split-bf16 core:
- * w3_split = cwfa_subnet_split_pack3x3_f32(torch weight [64,64,3,3]) (221184 bytes, 16-byte aligned); the 1x1 panel as for
- * cwfa_subnet_layer_f32. */
-int cwfa_subnet_split_pack3x3_f32(const float* w, void* packed, void* stream);
-int cwfa_subnet_layer_split_f32(const float* x, const void* w3_split, const float* b3, const float* w1_panel, const float* b1,
-                                float* y, int B, int H, int W, int64_t x_bs, int64_t y_bs, void* stream);
+/* The fused sub-network layer  y = ELU(W1 . ELU(conv3x3(x, W3) + b3) + b1 + x), 64 channels (networks.py:624-631,660-665)
+ * with BOTH convolutions on the split-bf16 core (three bf16 pieces per fp32 operand, six products, fp32 accumulation;
+ * `split_products` = 1: plain bf16 operands), one persistent launch (csrc/conv_split_layer.hip).
+ *   packed = cwfa_subnet_layer_split_pack_f32(w3 [64,64,3,3], w1 [64,64,1,1]): cwfa_subnet_layer_split_packed_bytes() bytes,
+ *   16-byte aligned, 40 slices (36 of the 3x3 bank by (chunk of 16 input channels, tap), 4 of the 1x1 bank). */
+int64_t cwfa_subnet_layer_split_packed_bytes(void);
+int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream);
+int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H,
+                                int W, int64_t x_bs, int64_t y_bs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Lenslet views (the step before the path): XLFMDatasetFull.extract_views XLFMDataset.py:212-242 followed by the

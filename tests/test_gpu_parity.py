@@ -879,9 +879,10 @@ def test_sharded_nll_two_ranks_on_the_gpu_path():
         assert abs(nll - float(ref)) <= 1e-6 * abs(float(ref)), (nll, float(ref))
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96)])
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96), (3, 16, 32), (1, 5, 3), (2, 130, 200)])
 def test_split_fused_layer_is_fp32_accurate(shape):
-    """The fused sub-network layer with its 3x3 on the split-bf16 core (experimental): same reference, same tolerance."""
+    """The fused sub-network layer with both convolutions on the split-bf16 core (persistent kernel, several tiles per
+    workgroup at the larger shapes, ragged borders): same reference, same tolerance as the fp32 MFMA layer."""
     from cwfa_amd import ops
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W + 1)
@@ -891,5 +892,5 @@ def test_split_fused_layer_is_fp32_accurate(shape):
     F = torch.nn.functional
     xd = x.double()
     ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
-    y = ops.subnet_layer(x.cuda(), ops.pack_split_layer_weight(w3.cuda()), b3.cuda(), ops.pack_1x1_panel(w1.cuda()), b1.cuda())
+    y = ops.subnet_layer(x.cuda(), ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda())
     assert_close(y, ref, 3e-6, "split fused layer")

@@ -52,7 +52,7 @@ x = torch.randn(1, 64, 512, 512, device="cuda")
 w3, b3 = torch.randn(64, 64, 3, 3, device="cuda") / 24, torch.randn(64, device="cuda") * 0.1
 w1, b1 = torch.randn(64, 64, 1, 1, device="cuda") / 8, torch.randn(64, device="cuda") * 0.1
 pn = ops.pack_1x1_panel(w1)
-pa, pb = ops.pack_conv_weight(w3), ops.pack_split_layer_weight(w3)
+pa, pb = ops.pack_conv_weight(w3), ops.pack_split_layer_weight(w3, w1)
 ya, yb = ops.subnet_layer(x, pa, b3, pn, b1), ops.subnet_layer(x, pb, b3, pn, b1)
 ta, tb = t(lambda: ops.subnet_layer(x, pa, b3, pn, b1), 20), t(lambda: ops.subnet_layer(x, pb, b3, pn, b1), 20)
 fl = 2.0 * 64 * 64 * 10 * 512 * 512
