@@ -41,7 +41,7 @@ def build_all(force=False, verbose=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn, file=sys.stderr)
-    if jobs or force or not os.path.exists(LIB):
+    if jobs or force or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     return LIB
 

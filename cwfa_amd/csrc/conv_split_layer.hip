@@ -3,27 +3,34 @@
 //     y = ELU( W1 . ELU( conv3x3(x, W3) + b3 ) + b1 + x ),   64 channels      (networks.py:624-631, 660-665)
 //
 // Every fp32 operand is split EXACTLY into three bf16 pieces (v = v1 + v2 + v3: 3 x 8 = 24 significand bits) and the six
-// partial products with i + j <= 4 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-24 relative).
+// partial products with i + j <= 4 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 relative).
 // With `products == 1` only the leading piece is used: plain bf16 operands (BASELINE.json configs[4]).
+// (16x16x32, not 32x32x16: under this load the chip is clock-limited by power and holds a 1.2x higher rate on the
+//  small shape -- tools/probe/mfma_shape.hip: 2200 vs 1800 TF/s bf16 with every operand re-read from LDS.)
 //
 // One PERSISTENT workgroup per CU (512 threads = 8 waves, two per SIMD) walks tiles of 64 channels x 16 rows x 32 pixels;
-// wave w owns image rows 2w, 2w+1 of the tile (two n-tiles) and both 32-channel m-tiles.  A tile is 40 steps of
-// 24 MFMAs per wave:
-//   steps  0..35  3x3 conv: 4 chunks of 16 input channels x 9 taps.  The haloed input tile of a chunk,
-//                 [piece 3][k half 2][18 rows][34 px] x 16 B (8 channels of one pixel = one B fragment), sits in one of
-//                 TWO LDS buffers; a tap only shifts the B-operand address by a constant.  The NEXT chunk (or the next
-//                 tile's first) is read from the fp32 tensor during the first three steps of a chunk (buffer loads: padding
-//                 and the image border come back as 0.0 from the range check), split and stored into the other buffer
-//                 in steps 4..6 -- the vector work rides beside the partner wave's MFMAs (bf16 MFMA and VALU are
-//                 separate pipes).
-//   steps 36..39  1x1 conv on the same cores: the 3x3 accumulators (+b3, ELU, split in registers) ARE its B operand,
-//                 register by register (the k order inside a step is permuted accordingly when W1 is packed).
-// Weights: 40 slices of 6 KB ([piece][k half][64 cout][8]) stream through a three-buffer LDS ring by LDS-DMA; the
-// slice of step s+3 is issued in step s into the buffer whose fragments the wave already holds in registers (the
-// A fragments of step s+1 are read during step s), one barrier per step.  Biases ride in the accumulator init.
+// wave w owns image rows 2w, 2w+1 of the tile = four n-tiles of 16 pixels, and all four 16-channel m-tiles
+// (16 accumulator tiles of 4 registers).  A tile is
+//   18 conv steps  K = 32 per MFMA = TWO (16-channel chunk, tap) units of the 36 a 3x3 over 64 channels has; lane group
+//                  g = lane >> 4 reads k-half g & 1 of unit g >> 1.  The haloed input tile of a chunk,
+//                  [piece 3][k half 2][18 rows][34 px] x 16 B (8 channels of one pixel = one B fragment), sits in one of
+//                  TWO LDS buffers (even / odd chunks); a tap only shifts the B-operand address.  Steps pair the taps
+//                  (0,1)(2,3)(4,5)(6,7) of an even chunk, tap 8 with tap 0 of the following odd chunk (both buffers
+//                  live), then (1,2)(3,4)(5,6)(7,8): the even buffer is free from the 6th step of such a 9-step period
+//                  and is refilled there (loads three steps earlier: buffer loads, padding and the image border come
+//                  back as 0.0 from the range check; split in registers, three 16-byte LDS stores per entry), the odd
+//                  buffer in the first three steps.  The vector work rides beside the partner wave's MFMAs.
+//   the 1x1 phase  per n-tile: the 3x3 accumulators (+b3 via the accumulator init, ELU, split in registers) ARE the B
+//                  operand of the 1x1 GEMM, register by register (the k order inside a step is permuted accordingly
+//                  when W1 is packed); its 16 results overwrite the accumulators they came from, and the epilogue
+//                  (+x, ELU, store) of n-tile i is slotted between the MFMAs of n-tile i+1.
+// Weights: 20 slices of 12 KB ([piece][k group 4][64 cout][8]) stream through a three-slot LDS ring by LDS-DMA; slice
+// s+2 is issued at the start of step s and verified at its end (one barrier per step, 19 per tile).
 #include "conv_internal.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include <utility>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
@@ -31,16 +38,17 @@ extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 
 namespace {
 
 constexpr int TR = 16, TC = 32, XR = TR + 2, XC = TC + 2;
-constexpr int XE = 2 * XR * XC;             // 1224 entries (k half, row, col) of 16 bytes per piece
-constexpr int XPB = XE * 16;                // bytes of one piece plane
-constexpr int XB = 3 * XPB;                 // bytes of one input buffer (58 752)
-constexpr int WSL = 3 * 2 * 64 * 16;        // bytes of one weight slice (6 144)
-constexpr int NSL = 40;                     // 36 slices of the 3x3 bank + 4 of the 1x1 bank
+constexpr int KHB = 9984;                   // bytes of one k-half plane: 18 x 34 x 16 = 9792 padded to a multiple of 256 (bank phase)
+constexpr int XPB = 2 * KHB;                // bytes of one piece plane
+constexpr int XB = 3 * XPB;                 // bytes of one input buffer (59 904)
+constexpr int WSL = 3 * 4 * 64 * 16;        // bytes of one weight slice (12 288)
+constexpr int NSL = 20;                     // 18 slices of the 3x3 bank + 2 of the 1x1 bank
 constexpr int OFF_W = 2 * XB;
-constexpr int OFF_DUMP = OFF_W + 3 * WSL;   // 2 KB: where waves 6, 7 send their (out-of-range, zero) share of a slice DMA
-constexpr int OFF_BIAS = OFF_DUMP + 2048;   // b3[64], b1[64]
-constexpr int LDS_BYTES = OFF_BIAS + 512;   // 138 496
+constexpr int OFF_DUMP = OFF_W + 3 * WSL;   // 4 KB: where waves 4..7 send their second (out-of-range, zero) slice DMA
+constexpr int OFF_BIAS = OFF_DUMP + 4096;   // b3[64], b1[64]
+constexpr int LDS_BYTES = OFF_BIAS + 512;   // 161 280
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int NE = 2 * XR * XC;             // 1224 staging entries (k half, row, col) per chunk
 
 struct LParams {
     const float* x;
@@ -65,8 +73,6 @@ __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
-
 __device__ __forceinline__ float elu(float v) {
     const float e = __expf(v) - 1.0f;
     return v > 0.f ? v : e;
@@ -84,32 +90,45 @@ __device__ __forceinline__ void split3(float v, __bf16& a1, __bf16& a2, __bf16& 
     }
 }
 
-#define MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// (chunk, tap) unit u = 0..35 of the 3x3: byte offset of its B fragments relative to the lane base
+__host__ __device__ constexpr int unit_off(int u) {
+    const int chunk = u / 9, tap = u % 9;
+    return (chunk & 1) * XB + ((tap / 3) * XC + tap % 3) * 16;
+}
 
 template <bool SIX>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
     const int HW = p.H * p.W;
     const int plane = HW * 4;
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int NQ = SIX ? 3 : 1;
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
-    // ---- staging entries e = tid + k*512 < XE of the [k half][18 rows][34 px] tile: geometry inside the tile
+    // ---- staging entries e = tid + k*512 < NE of the [k half][18 rows][34 px] tile
     int er[3], ec[3], eh[3];
     bool fin[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int e = tid + k * 512;
-        fin[k] = e < XE;
+        fin[k] = e < NE;
         ec[k] = e % XC;
         er[k] = (e / XC) % XR;
-        eh[k] = e / (XR * XC);
+        eh[k] = (e / (XR * XC)) & 1;
     }
-    const bool stage2 = wave < 4;              // entry 2 exists only for tid < 200 (uniform per wave up to wave 3)
-
-    float xv[3][8];
-    unsigned fo[3];
+    const bool stage2 = wave < 4;              // entry 2 exists only for tid < 200: waves 0..3 (wave 3 partly)
+    auto entry_offsets = [&](bool valid, int row0, int col0, unsigned (&fo)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int gr = row0 + er[k] - 1, gc = col0 + ec[k] - 1;
+            const bool ok = valid && fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
+            fo[k] = ok ? (unsigned)((eh[k] * 8 * HW + gr * p.W + gc) * 4) : OOB;
+        }
+    };
     auto rsrc_of = [&](const float* base) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 64 * plane, 0x00020000);
     };
@@ -121,68 +140,59 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         row0 = ty * TR;
         col0 = (rem - ty * p.tiles_x) * TC;
     };
-    auto set_stage_tile = [&](bool valid, int row0, int col0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int gr = row0 + er[k] - 1, gc = col0 + ec[k] - 1;
-            const bool ok = valid && fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-            fo[k] = ok ? (unsigned)((eh[k] * 8 * HW + gr * p.W + gc) * 4) : OOB;
-        }
-    };
-    auto load_entry = [&](auto kc, const float* base, int chunk) {
-        constexpr int k = decltype(kc)::value;
+    auto load_entry = [&](float (&xv)[8], const float* base, unsigned fo, int chunk) {
         const auto rs = rsrc_of(base);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            xv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, fo[k], (chunk * 16 + j) * plane, 0));
+            xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, fo, (chunk * 16 + j) * plane, 0));
     };
-    auto store_entry = [&](auto kc, int buf) {
+    auto store_entry = [&](auto kc, const float (&xv)[8], int buf) {
         constexpr int k = decltype(kc)::value;
         if (k == 2 && !stage2) return;
         bf16x8 pc[3];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __bf16 a1, a2 = (__bf16)0.f, a3 = (__bf16)0.f;
-            split3<SIX>(xv[k][j], a1, a2, a3);
+            split3<SIX>(xv[j], a1, a2, a3);
             pc[0][j] = a1; pc[1][j] = a2; pc[2][j] = a3;
         }
         if (fin[k]) {
-            char* dst = lds + buf * XB + (tid + k * 512) * 16;
+            char* dst = lds + buf * XB + eh[k] * KHB + (er[k] * XC + ec[k]) * 16;
 #pragma unroll
-            for (int q = 0; q < (SIX ? 3 : 1); ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
+            for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
         }
     };
 
-    // ---- weight slices: 384 x 16 B, waves 0..5 carry one KB each; waves 6, 7 issue the same instruction into the dump area
+    // ---- weight slices: 12 x 1 KB; every wave issues two DMA instructions (waves 4..7: the second into the dump area)
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, NSL * WSL, 0x00020000);
-    const unsigned dma_off = wave < 6 ? (unsigned)tid * 16u : OOB;
-    auto dma_w = [&](int slice, int wb) {
-        char* dst = lds + (wave < 6 ? OFF_W + wb * WSL + wave * 1024 : OFF_DUMP + (wave - 6) * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, dma_off, slice * WSL, 0, 0);
+    auto dma_w = [&](int slice, int slot) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + OFF_W + slot * WSL + wave * 1024), 16, (unsigned)tid * 16u,
+                                                 slice * WSL, 0, 0);
+        char* d2 = lds + (wave < 4 ? OFF_W + slot * WSL + 8192 + wave * 1024 : OFF_DUMP + (wave - 4) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)d2, 16, wave < 4 ? 8192u + (unsigned)tid * 16u : OOB, slice * WSL, 0, 0);
     };
+    auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
 
-    const char* alane = lds + OFF_W + (kh * 64 + l31) * 16;                               // + wb*WSL + (q*128 + m*32)*16
-    const char* blane = lds + ((kh * XR + 2 * wave) * XC + l31) * 16;                     // + buf*XB + q*XPB + ((n+dy)*XC + dx)*16
-    const float* bias = reinterpret_cast<const float*>(lds + OFF_BIAS);
+    const int alane = OFF_W + (g * 64 + c16) * 16;                            // + slot*WSL + (q*256 + mt*16)*16
+    const int blane = (g & 1) * KHB + ((2 * wave) * XC + c16) * 16;           // + unit_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
+    const bool sel = (g >> 1) != 0;                                           // lane groups 2, 3 read the step's second unit
+    const f32x4* bias4 = reinterpret_cast<const f32x4*>(lds + OFF_BIAS);     // [b3 16 x 4][b1 16 x 4]
 
-    bf16x8 A[2][2][3], Bq[2][3];
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];
+    bf16x8 A[2][3], Bq[4][3];
+    float xa[3][8], xb[3][8];                   // staged entries of the next even / odd chunk
+    unsigned fo_c[3], fo_n[3];                  // entry offsets in the current / next tile
 
-    auto read_a = [&](auto setc, int wb) {
-        constexpr int set = decltype(setc)::value;
+    auto read_a = [&](int set, int abase, int mt) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < (SIX ? 3 : 1); ++q)
-                A[set][m][q] = *reinterpret_cast<const bf16x8*>(alane + wb * WSL + (q * 128 + m * 32) * 16);
+        for (int q = 0; q < NQ; ++q) A[set][q] = *reinterpret_cast<const bf16x8*>(lds + abase + (q * 256 + mt * 16) * 16);
     };
-    auto read_b = [&](int n, int buf, int dy, int dx) {
+    auto read_b = [&](int nt, int bbase) {
 #pragma unroll
-        for (int q = 0; q < (SIX ? 3 : 1); ++q)
-            Bq[n][q] = *reinterpret_cast<const bf16x8*>(blane + buf * XB + q * XPB + ((n + dy) * XC + dx) * 16);
+        for (int q = 0; q < NQ; ++q)
+            Bq[nt][q] = *reinterpret_cast<const bf16x8*>(lds + bbase + q * XPB + ((nt >> 1) * XC + 16 * (nt & 1)) * 16);
     };
-    // six products of one (m, n) pair, smallest terms first; A fragments from register set `set`
-    auto mfma6 = [&](f32x16& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    auto mfma6 = [&](f32x4& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
         if constexpr (SIX) {
             MFMA(a[2], b[0], c);
             MFMA(a[1], b[1], c);
@@ -192,191 +202,216 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         }
         MFMA(a[0], b[0], c);
     };
+    auto bbase_of = [&](int offA, int offB) { return blane + (sel ? offB : offA); };
 
     // ---------------------------------------------------------------------------------------------- prologue
     if (tid < 128) reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = tid < 64 ? p.b3[tid] : p.b1[tid - 64];
     int tile = blockIdx.x;
     int tb, row0, col0;
     tile_coords(tile, tb, row0, col0);
-    const float* xs_cur = p.x + (int64_t)tb * p.x_bs;         // sample the staging loads of this tile's chunks read
-    set_stage_tile(true, row0, col0);
-    sfor<3>([&](auto kc) { load_entry(kc, xs_cur, 0); });
+    const float* xs_cur = p.x + (int64_t)tb * p.x_bs;
+    entry_offsets(true, row0, col0, fo_c);
+    sfor<3>([&](auto kc) { load_entry(xa[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 0); });
+    sfor<3>([&](auto kc) { load_entry(xb[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 1); });
     dma_w(0, 0);
-    dma_w(1, 1);
-    dma_w(2, 2);
-    sfor<3>([&](auto kc) { store_entry(kc, 0); });
+    sfor<3>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], 0); });
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_a(ic<0>{}, 0);
-    read_b(0, 0, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();           // every wave holds slice 0: step 0 may overwrite its buffer
-    int wb = 0;                             // ring buffer of the current step's slice
+    int cs = 0;                                  // ring slot of the current step's slice
+    read_a(0, alane, 0);
+    {
+        const int bb = bbase_of(unit_off(0), unit_off(1));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) read_b(nt, bb);
+    }
 
     for (; tile < p.ntiles; tile += gridDim.x) {
-        // next tile (staged during this tile's last chunk)
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < p.ntiles;
         int nb, nrow0, ncol0;
         tile_coords(has_next ? ntile : tile, nb, nrow0, ncol0);
         const float* xs_next = p.x + (int64_t)nb * p.x_bs;
+        entry_offsets(has_next, nrow0, ncol0, fo_n);
 
-        // accumulators start from the conv bias
+        // accumulators start from the conv bias (channel mt*16 + 4g + r)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 bv = bias4[mt * 4 + g];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = bias[m * 32 + acc_row(r, kh)];
-                acc[m][0][r] = bv;
-                acc[m][1][r] = bv;
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = bv;
+        }
+
+        // ------------------------------------------------------------------------------------------ 18 conv steps
+        sfor<18>([&](auto sc) {
+            constexpr int S = decltype(sc)::value, P = S % 9, PER = S / 9;
+            // -- the slice DMA(s) first, then this step's staging loads (which may stay in flight across the barrier)
+            const int s1 = next_slot(cs), s2 = next_slot(s1);
+            if constexpr (S == 0) dma_w(1, s1);                 // (late by one step: the 1x1 phase counts as one)
+            dma_w(S + 2, s2);
+            constexpr bool LOADS = (P >= 2 && P <= 4) || P >= 6;
+            if constexpr (P >= 2 && P <= 4) {                   // even chunk 2*PER+2 (PER = 1: chunk 0 of the next tile)
+                constexpr int k = P - 2;
+                if constexpr (PER == 0) load_entry(xa[k], xs_cur, fo_c[k], 2);
+                else load_entry(xa[k], xs_next, fo_n[k], 0);
             }
-
-        // -------------------------------------------------------------------------------- 3x3: chunks of 16 channels
-        auto chunk_steps = [&](auto parc, int chunk) {
-            constexpr int PAR = decltype(parc)::value;            // input buffer of this chunk; A register set parity
-            const bool last = chunk == 3;
-            if (last) set_stage_tile(has_next, nrow0, ncol0);
-            const float* xs = last ? xs_next : xs_cur;
-            const int nchunk = last ? 0 : chunk + 1;
-            sfor<9>([&](auto tc) {
-                constexpr int TAP = decltype(tc)::value, dy = TAP / 3, dx = TAP % 3, set = (PAR + TAP) & 1;
-                constexpr int NT = (TAP + 1) % 9, ndy = NT / 3, ndx = NT % 3;
-                constexpr int S = TAP;                              // slice index inside the chunk
-                // staging loads of the next chunk first, then this step's slice DMA (slice s+3 -> the buffer of slice s)
-                if constexpr (TAP < 3) load_entry(ic<TAP>{}, xs, nchunk);
-                {
-                    int sl = chunk * 9 + S + 3;
-                    sl = sl >= NSL ? sl - NSL : sl;
-                    dma_w(sl, wb);
+            if constexpr (P >= 6) {                             // odd chunk 2*PER+3 (PER = 1: chunk 1 of the next tile)
+                constexpr int k = P - 6;
+                if constexpr (PER == 0) load_entry(xb[k], xs_cur, fo_c[k], 3);
+                else load_entry(xb[k], xs_next, fo_n[k], 1);
+            }
+            const int ab = alane + cs * WSL;
+            if constexpr (S == 1) read_a(0, ab, 0);             // slice 1 became visible with the barrier of step 0
+            constexpr int NS = (S + 1) % 18;                    // next step's B base (step 17: unused, the 1x1 phase follows)
+            const int bbn = bbase_of(unit_off(2 * NS), unit_off(2 * NS + 1));
+            FENCE();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt < 3) read_a((mt + 1) & 1, ab, mt + 1);
+                else if (S != 0 && S != 17) read_a(0, alane + s1 * WSL, 0);    // first fragments of the next step
+                FENCE();
+#pragma unroll
+                for (int np = 0; np < 4; np += 2) {
+                    mfma6(acc[mt][np], A[mt & 1], Bq[np]);
+                    mfma6(acc[mt][np + 1], A[mt & 1], Bq[np + 1]);
+                    FENCE();
+                    if (mt == 3 && S != 17) {
+                        read_b(np, bbn);
+                        read_b(np + 1, bbn);
+                        FENCE();
+                    }
                 }
-                const int wb1 = wb == 2 ? 0 : wb + 1;
-                read_b(1, PAR, dy, dx);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(acc[0][0], A[set][0], Bq[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                read_a(ic<set ^ 1>{}, wb1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(acc[1][0], A[set][1], Bq[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (TAP >= 4 && TAP < 7) store_entry(ic<TAP - 4>{}, PAR ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(acc[0][1], A[set][0], Bq[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                // first B fragment of the next step (tap 8: the next chunk's tile, complete since the barrier of step 6)
-                read_b(0, TAP == 8 ? PAR ^ 1 : PAR, ndy, ndx);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(acc[1][1], A[set][1], Bq[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                // the DMA of the previous step (slice s+2) has landed; this step's own loads may stay in flight
-                if constexpr (TAP < 3) asm volatile("s_waitcnt vmcnt(9)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                wb = wb1;
-            });
-        };
-        chunk_steps(ic<0>{}, 0);
-        chunk_steps(ic<1>{}, 1);
-        chunk_steps(ic<0>{}, 2);
-        chunk_steps(ic<1>{}, 3);
-
-        // -------------------------------------------------------------------------------- 1x1 on the hidden accumulators
-        f32x16 acc2[2][2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = bias[64 + m * 32 + acc_row(r, kh)];
-                acc2[m][0][r] = bv;
-                acc2[m][1][r] = bv;
-            }
-        sfor<4>([&](auto kcc) {
-            constexpr int KC = decltype(kcc)::value, set = KC & 1, hm = KC >> 1, r0 = 8 * (KC & 1);
-            {
-                int sl = 36 + KC + 3;
-                sl = sl >= NSL ? sl - NSL : sl;
-                dma_w(sl, wb);
-            }
-            const int wb1 = wb == 2 ? 0 : wb + 1;
-            bf16x8 Hq[2][3];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    __bf16 a1, a2 = (__bf16)0.f, a3 = (__bf16)0.f;
-                    split3<SIX>(elu(acc[hm][n][r0 + j]), a1, a2, a3);
-                    Hq[n][0][j] = a1; Hq[n][1][j] = a2; Hq[n][2][j] = a3;
+                // the vector-heavy part of staging after the first m-tile: split + LDS stores of one entry
+                if (mt == 0) {
+                    if constexpr (P <= 2) store_entry(ic<P>{}, xb[P], 1);
+                    if constexpr (P >= 5 && P <= 7) store_entry(ic<P - 5>{}, xa[P - 5], 0);
+                    FENCE();
                 }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc2[0][0], A[set][0], Hq[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(ic<set ^ 1>{}, wb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc2[1][0], A[set][1], Hq[0]);
-            mfma6(acc2[0][1], A[set][0], Hq[1]);
-            mfma6(acc2[1][1], A[set][1], Hq[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            // this step's slice DMA has landed; its 8 staging loads (issued after it) may stay in flight
+            // (LDS: everything but the 12 youngest operations -- the B fragments just requested for the next step -- is done:
+            //  this step's staging stores, and every read of the weight slot and input buffer that get overwritten next)
+            if constexpr (LOADS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (S != 17 && SIX) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            wb = wb1;
+            cs = s1;
         });
 
-        // -------------------------------------------------------------------------------- residual, ELU, store
+        // ------------------------------------------------------------------------------------------ 1x1 + epilogue
         {
-            // buffer accesses: a lane outside the image carries an out-of-range offset (loads give 0.0, stores are dropped),
-            // the channel rides in the scalar offset -- no address arithmetic and no branches per element
+            const int sw0 = cs, sw1 = next_slot(cs), sn0 = next_slot(sw1);         // W1 slices, next tile's slice 0
+            dma_w(0, sn0);
             const auto rx = rsrc_of(p.x + (int64_t)tb * p.x_bs);
             const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)tb * p.y_bs, 0, 64 * plane, 0x00020000);
-            const int col = col0 + l31;
-            unsigned oo[2];
+            unsigned oo[4];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int row = row0 + 2 * wave + n;
-                oo[n] = (col < p.W && row < p.H) ? (unsigned)(row * p.W + col) * 4u + (unsigned)kh * 4u * (unsigned)plane : OOB;
+            for (int nt = 0; nt < 4; ++nt) {
+                const int row = row0 + 2 * wave + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+                oo[nt] = (col < p.W && row < p.H) ? (unsigned)(row * p.W + col) * 4u + (unsigned)g * 4u * (unsigned)plane : OOB;
             }
-            f32x16 res[2];
-            auto load_res = [&](int g, f32x16& rv) {
-                const int m = g >> 1, n = g & 1;
+            f32x4 res[2][4];
+            auto load_res = [&](int nt, f32x4 (&rv)[4]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, oo[n], (m * 32 + acc_row(r, 0)) * plane, 0));
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[mt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, oo[nt], (mt * 16 + r) * plane, 0));
             };
-            load_res(0, res[0]);
+            // +x, ELU, store of two of the 16 results of n-tile nt (piece i = 0..7)
+            auto epilogue_piece = [&](int nt, int i, const f32x4 (&rv)[4]) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int m = g >> 1, n = g & 1;
-                if (g < 3) load_res(g + 1, res[(g + 1) & 1]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = elu(acc2[m][n][r] + res[g & 1][r]);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, oo[n], (m * 32 + acc_row(r, 0)) * plane, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const int mt = i >> 1, r = (i & 1) * 2 + h;
+                    const float v = elu(acc[mt][nt][r] + rv[mt][r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, oo[nt], (mt * 16 + r) * plane, 0);
                 }
+            };
+            const int a0 = alane + sw0 * WSL, a1 = alane + sw1 * WSL;
+            bf16x8 A1[2][2][3];                     // two sets of W1 fragments: sub-block i = (m-tile pair i >> 1, k step i & 1)
+            auto read_a1 = [&](int i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        A1[i & 1][h][q] = *reinterpret_cast<const bf16x8*>(lds + ((i & 1) ? a1 : a0) + (q * 256 + ((i >> 1) * 2 + h) * 16) * 16);
+            };
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                // hidden map of this n-tile -> B fragments of the two k steps: element j of lane group g = channel
+                // 16*(2s + (j>>2)) + 4g + (j&3) = register j&3 of accumulator tile 2s + (j>>2)
+                bf16x8 Hq[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 h1, h2 = (__bf16)0.f, h3 = (__bf16)0.f;
+                        split3<SIX>(elu(acc[2 * s + (j >> 2)][nt][j & 3]), h1, h2, h3);
+                        Hq[s][0][j] = h1; Hq[s][1][j] = h2; Hq[s][2][j] = h3;
+                    }
+                load_res(nt, res[nt & 1]);          // consumed by this n-tile's epilogue, one iteration later
+                read_a1(0);
+                FENCE();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // (m-tile pair, k step): 12 MFMAs on two accumulator tiles
+                    const int mp = (i >> 1) * 2, s = i & 1;
+                    if (i + 1 < 4) read_a1(i + 1);
+                    if (s == 0) {
+                        acc[mp][nt] = bias4[16 + mp * 4 + g];
+                        acc[mp + 1][nt] = bias4[16 + (mp + 1) * 4 + g];
+                    }
+                    FENCE();
+                    mfma6(acc[mp][nt], A1[i & 1][0], Hq[s]);
+                    mfma6(acc[mp + 1][nt], A1[i & 1][1], Hq[s]);
+                    FENCE();
+                    if (nt > 0) {
+                        epilogue_piece(nt - 1, 2 * i, res[(nt - 1) & 1]);
+                        epilogue_piece(nt - 1, 2 * i + 1, res[(nt - 1) & 1]);
+                        FENCE();
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) epilogue_piece(3, i, res[1]);
+            // slice 0 of the next tile (issued at the start of this phase) has landed; the 16 youngest stores may stay in flight
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cs = sn0;
+            read_a(0, alane + cs * WSL, 0);
+            {
+                const int bb = bbase_of(unit_off(0), unit_off(1));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) read_b(nt, bb);
             }
         }
         tb = nb; row0 = nrow0; col0 = ncol0;
         xs_cur = xs_next;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fo_c[k] = fo_n[k];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slice DMAs issued past the end
 }
 
-// packed image: 40 slices [piece 3][k half 2][64 cout][8] of bf16.
-//   slices 0..35  (chunk c, tap t): element j of half h = w3[co][c*16 + h*8 + j][t]
-//   slices 36..39 (k step kc of the 1x1): element j of half h = w1[co][ch], ch = 16*kc + 8*(j>>2) + 4*h + (j&3)
-//                 -- the hidden channel that register 8*(kc&1) + j of accumulator tile kc>>1 holds in lane half h
+// packed image: 20 slices [piece 3][k group 4][64 cout][8] of bf16.
+//   slices 0..17 (conv step s): group g = unit u = 2s + (g >> 1) = (chunk u / 9, tap u % 9), k half g & 1:
+//                 element j = w3[co][chunk*16 + (g&1)*8 + j][tap]
+//   slices 18, 19 (k step s of the 1x1): element j of group g = w1[co][16*(2s + (j>>2)) + 4g + (j&3)] -- the hidden
+//                 channel that register j & 3 of accumulator tile 2s + (j >> 2) holds in lane group g
 __global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w1,
                                                                uint4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice 40][h 2][co 64]
-    if (i >= NSL * 128) return;
-    const int co = i % 64, h = (i / 64) % 2, sl = i / 128;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice 20][g 4][co 64]
+    if (i >= NSL * 256) return;
+    const int co = i % 64, g = (i / 64) % 4, sl = i / 256;
     unsigned short pc[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v;
-        if (sl < 36) {
-            const int c = sl / 9, t = sl % 9;
-            v = w3[((int64_t)co * 64 + c * 16 + h * 8 + j) * 9 + t];
+        if (sl < 18) {
+            const int u = 2 * sl + (g >> 1), c = u / 9, t = u % 9;
+            v = w3[((int64_t)co * 64 + c * 16 + (g & 1) * 8 + j) * 9 + t];
         } else {
-            const int kc = sl - 36;
-            v = w1[co * 64 + 16 * kc + 8 * (j >> 2) + 4 * h + (j & 3)];
+            const int s = sl - 18;
+            v = w1[co * 64 + 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)];
         }
         __bf16 a1, a2, a3;
         split3<true>(v, a1, a2, a3);
@@ -391,7 +426,7 @@ __global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __re
         u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
         u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
         u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
-        out[(sl * 3 + q) * 128 + h * 64 + co] = u;
+        out[(sl * 3 + q) * 256 + g * 64 + co] = u;
     }
 }
 
@@ -404,7 +439,7 @@ extern "C" int64_t cwfa_subnet_layer_split_packed_bytes(void) { return (int64_t)
 extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream) {
     CWFA_REQUIRE(w3 && w1 && packed, CWFA_E_INVAL, "cwfa_subnet_layer_split_pack_f32: null pointer");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_split_pack_f32: packed image must be 16-byte aligned");
-    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((NSL * 128 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w1,
+    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((NSL * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w1,
                        reinterpret_cast<uint4*>(packed));
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_split_pack_f32");
     return CWFA_OK;

@@ -49,6 +49,42 @@ __global__ __launch_bounds__(512, 1) void k32(const uint4* __restrict__ src, flo
     out[blockIdx.x * 512 + threadIdx.x] = s + (float)(t1 - t0) * 1e-30f;
 }
 
+template <int NT, bool BAR, bool PAIR>
+__global__ __launch_bounds__(NT, 1) void k16v(const uint4* __restrict__ src, float* out, int reps) {
+    __shared__ uint4 lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += NT) lds[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16x8* base = reinterpret_cast<const bf16x8*>(lds) + lane + wave * 64;
+    f32x4 acc[4][4] = {};
+    for (int r = 0; r < reps; ++r) {
+        bf16x8 A[4][3], B[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                A[m][q] = base[((r * 24 + m * 3 + q) * 512) & 3071];
+                B[m][q] = base[((r * 24 + 12 + m * 3 + q) * 512 + 64) & 3071];
+            }
+        constexpr int qa[6] = {2, 1, 0, 1, 0, 0}, qb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; n += (PAIR ? 2 : 1))
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m][qa[pr]], B[n][qb[pr]], acc[m][n], 0, 0, 0);
+                    if (PAIR) acc[m][n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m][qa[pr]], B[n + 1][qb[pr]], acc[m][n + 1], 0, 0, 0);
+                }
+        if (BAR) __syncthreads();
+    }
+    float s = 0;
+    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 4; ++n)
+            for (int j = 0; j < 4; ++j) s += acc[m][n][j];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(512, 1) void k16(const uint4* __restrict__ src, float* out, int reps) {
     __shared__ uint4 lds[4096];
     for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = src[i];
@@ -149,6 +185,17 @@ int main() {
         const double fl = 256.0 * 8 * reps32 * 24 * 2.0 * 32 * 32 * 16;
         printf("round %d: 32x32x16 %.3f ms = %.0f TF/s bf16 (%.0f TF/s fp32-equivalent) | 16x16x32 chained %.3f ms = %.0f TF/s (%.0f) | 16x16x32 interleaved %.3f ms = %.0f TF/s (%.0f)\n",
                round, t32, fl / t32 / 1e9, fl / t32 / 6e9, t16, fl / t16 / 1e9, fl / t16 / 6e9, t16i, fl / t16i / 1e9, fl / t16i / 6e9);
+    }
+    {
+        const double fl2 = 256.0 * 8 * reps16 * 96 * 2.0 * 16 * 16 * 32;
+        auto rep = [&](const char* name, float t, double fl) { printf("%-44s %.3f ms = %.0f TF/s bf16\n", name, t, fl / t / 1e9); };
+        rep("16x16x32 2 waves/SIMD chained", timed([&] { k16v<512, false, false><<<256, 512>>>(src, out, reps16); }, 10), fl2);
+        rep("16x16x32 2 waves/SIMD pair-interleaved", timed([&] { k16v<512, false, true><<<256, 512>>>(src, out, reps16); }, 10), fl2);
+        rep("16x16x32 2 waves/SIMD chained + barrier/96", timed([&] { k16v<512, true, false><<<256, 512>>>(src, out, reps16); }, 10), fl2);
+        rep("16x16x32 2 waves/SIMD pair + barrier/96", timed([&] { k16v<512, true, true><<<256, 512>>>(src, out, reps16); }, 10), fl2);
+        rep("16x16x32 1 wave/SIMD chained", timed([&] { k16v<256, false, false><<<256, 256>>>(src, out, reps16); }, 10), fl2 / 2);
+        rep("16x16x32 1 wave/SIMD pair-interleaved", timed([&] { k16v<256, false, true><<<256, 256>>>(src, out, reps16); }, 10), fl2 / 2);
+        rep("16x16x32 1 wave/SIMD pair + barrier/96", timed([&] { k16v<256, true, true><<<256, 256>>>(src, out, reps16); }, 10), fl2 / 2);
     }
     return 0;
 }
