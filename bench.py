@@ -9,9 +9,17 @@ LRNN (train mode, as CWFA.py:532) -> for n = 3..0: condition net Omega_n, 5 coup
 (config 3 of BASELINE.json: 4-scale CWFA + LRNN, CAT blocks, main.py defaults).  Every rank reconstructs its own
 independent volumes (weak scaling, no data-path collective); value = all volumes of all ranks / max-over-ranks time.
 
-Extra objects on the JSON line: `roofline` (dominant kernel, HIP events on the launch stream inside the timed region),
-`roofline_dwt` (the standalone Haar kernels of the DWT stage, the north_star's 60 %-of-HBM target), `cpu_baseline`
-(the CPU oracle timed on this host, rank 0, N=1 only).
+Arithmetic of the timed region (`--precision`, default "split"): fp32 tensors, fp32 accumulation, every convolution
+product formed from an EXACT three-way bf16 split of both fp32 operands (six bf16 MFMA products per fp32 product, dropped
+terms <= 2^-24 relative): fp32-equivalent arithmetic on the bf16 matrix pipe; full-size parity under the fp32 bound in
+tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle.  The same step on the plain fp32 MFMA kernels is measured
+after the timed region and stays on the line as `fp32_mfma`.
+
+Extra objects on the JSON line: `roofline` / `roofline_second` (the two conv kernels with the largest time share, HIP
+events on the launch stream), `roofline_dwt` (the in-path fused chain kernel that holds the inverse Haar; the standalone
+Haar kernel as a secondary field), `forward_nll` (BASELINE.json configs[3]: batch 4 per GPU, four flow steps + condition
+nets, one all-reduce of the NLL sums at N > 1), `fp32_mfma`, `bf16` (configs[4]), `experiment_train_step`,
+`cpu_baseline` (the CPU oracle timed on this host, rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -25,16 +33,21 @@ sys.path.insert(0, ROOT)
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+SPLIT_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product in "split" precision
+
+WINO2D_MIN = 512      # the library's "winograd_2d" default (ops.WINOGRAD_2D_DEFAULT); --wino2d overrides both
 
 
 def family(key):
-    """The kernel instantiation a conv launch runs (mirrors the dispatch in csrc/conv2d.hip / conv_wino.hip), i.e. ONE
-    kernel name in a rocprofv3 trace: launches of one family differ only in Cin / H / W / B."""
+    """The kernel instantiation a conv launch runs (mirrors the dispatch in csrc/conv2d.hip / conv_wino.hip /
+    conv_split_layer.hip), i.e. ONE kernel name in a rocprofv3 trace: launches of one family differ only in Cin/H/W/B."""
     ks, cin, cout, H, W, B, tag = key[:7]
     if ks == "L":
-        return "wino_layer_kernel"
+        return "split_layer_kernel" if tag.endswith("+split") else "wino_layer_kernel"
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
@@ -44,33 +57,23 @@ def family(key):
     return "conv2d_mfma_kernel<k%d,%s>[%s]" % (ks, "co<=32" if cout <= 32 else "co<=64" if cout <= 64 else "co>64", tag)
 
 
-WINO2D_MIN = 512      # the library's "winograd_2d" default (ops.WINOGRAD_2D_DEFAULT); --wino2d overrides both
-
-
 def issued_factor(fam):
-    """MFMA work actually issued / algorithmic FLOPs of a kernel family (Winograd kernels issue fewer)."""
+    """Matrix-core products actually issued per algorithmic multiply-add of a kernel family, and the pipe they run on.
+    fp32 MFMA kernels: Winograd issues fewer (2/3 for F(2,3), 4/9 for F(2x2,3x3), 0.7 for the fused layer = nine F(2,3)
+    taps + one direct 1x1 tap of ten).  Split kernels: six bf16 products (one in plain-bf16 mode) per fp32 product."""
+    if "split" in fam:
+        return float(SPLIT_PRODUCTS), "bf16"
     if fam == "wino_layer_kernel":
-        return 0.7                     # nine F(2,3) taps (x 2/3) + one direct 1x1 tap, of ten algorithmic
+        return 0.7, "f32"
     if "wino2d" in fam:
-        return 4.0 / 9.0               # F(2x2,3x3): 16 products per 4 outputs instead of 36
+        return 4.0 / 9.0, "f32"
     if "wino" in fam:
-        return 2.0 / 3.0               # F(2,3) along one axis
-    return 1.0
-
-
-# family -> substring of the kernel's name in a rocprofv3 trace (template arguments: config, epilogue id, prologue flag)
-ROCPROF_NAMES = {
-    "wino_layer_kernel": "wino_layer_kernel",
-    "conv3x3_wino_kernel<W128>[pro|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, true>",
-    "conv3x3_wino_kernel<W128>[|prelu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, false>",
-    "conv3x3_wino_kernel<W128>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 2, false>",
-    "conv3x3_wino_kernel<W64>[|elu|||]": "conv3x3_wino_kernel<WCfg<8, 2, 1, 8>, 2, false>",
-    "conv3x3_wino2d_kernel[|prelu|||]": "conv3x3_wino2d_kernel<2, false, true>",
-}
+        return 2.0 / 3.0, "f32"
+    return 1.0, "f32"
 
 
 class ConvEvents:
-    """Event sink for ops.conv2d: everything (selection pass) or the launches of one kernel family (timed region)."""
+    """Event sink for ops.conv2d / ops.subnet_layer: everything (selection pass) or the launches of some kernel families."""
 
     def __init__(self, only=None):
         self.only, self.rows = only, []
@@ -106,6 +109,28 @@ def conv_bytes(key):
     return 4.0 * (cin * (2 if key[7] else 1) + cout) * H * W * B
 
 
+def roofline_of(fam, t_ms, n, flops, shapes, products, share=None, all_conv_ms=None):
+    """Roofline object of one conv kernel family.  `algorithmic_tflops` = direct-convolution FLOPs (2*Cout*Cin*taps*H*W
+    per launch) / summed HIP-event time; `achieved` = the matrix-core FLOPs the kernel ISSUES for
+    them (algorithmic x issued factor) / the same time, against the dense peak of the pipe it runs on: `frac` <= 1."""
+    factor, pipe = issued_factor(fam)
+    if pipe == "bf16":
+        factor = float(products)
+    peak = PEAK_BF16_MFMA_TFLOPS if pipe == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    alg = flops / (t_ms * 1e-3) / 1e12
+    inst = ("v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, %d bf16 products per fp32 product" % products) if pipe == "bf16" else \
+        "v_mfma_f32_32x32x2_f32" + (", Winograd: %.2fx the algorithmic MFMA count is issued" % factor if factor != 1.0 else "")
+    r = {"bound": "mfma", "achieved": alg * factor, "peak": peak, "unit": "TFLOP/s", "frac": alg * factor / peak, "traffic": None,
+         "kernel": "%s (%s)" % (fam, inst), "algorithmic_tflops": alg, "issued_per_algorithmic": factor,
+         "shapes": [dict(zip(("ks", "cin", "cout", "H", "W", "B", "launches"), (*k[:6], c)))
+                    for k, c in sorted(shapes.items(), key=lambda kv: -kv[1])][:6],
+         "flops_per_launch": flops / n, "algorithmic_bytes_per_launch": sum(conv_bytes(k) * c for k, c in shapes.items()) / n,
+         "avg_launch_ms": t_ms / n, "launches_timed": n}
+    if share is not None:
+        r["share_of_conv_time"], r["all_conv_ms_per_step"] = share, all_conv_ms
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,18 +139,19 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="volumes per step per GPU")
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--depths", type=int, default=96)
+    ap.add_argument("--precision", choices=("split", "fp32", "bf16"), default="split",
+                    help="arithmetic of the timed region: split = fp32-equivalent (exact three-way bf16 split of both operands, "
+                         "six products, fp32 accumulation) on the bf16 matrix cores [default]; fp32 = plain fp32 MFMA kernels; "
+                         "bf16 = BASELINE.json configs[4] (bf16 conv operands, restated tolerance; NOT the headline metric)")
+    ap.add_argument("--block-type", default="CAT", choices=("CAT", "GLOW", "AI1", "RNVP", "GIN"),
+                    help="coupling block of the flow steps (main.py --INN_block_type; CAT is the reference's default and the "
+                         "headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="the complete SURVEY 8d protocol on the full volume "
+                    "(warm-up + median of 3, all cores and 8 threads): several minutes")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
-    ap.add_argument("--no-experiment", action="store_true", help="skip the extra split-bf16 measurement after the timed region")
+    ap.add_argument("--no-experiment", action="store_true", help="skip the extra measurements after the timed region")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
-    ap.add_argument("--no-materialize-up", action="store_true", help="(tuning) the same for the UNet's transposed convolutions")
-    ap.add_argument("--no-materialize", action="store_true", help="(tuning) UNet BatchNorm applied on load instead of materialised")
-    ap.add_argument("--bf16", action="store_true", help="BASELINE.json configs[4] (NOT the headline configuration): bf16 operands in "
-                    "the heavy convolutions, fp32 accumulation; the line's dtype says so")
-    ap.add_argument("--split-bf16", type=int, default=0, choices=(0, 1, 2),
-                    help="(experiment, NOT the headline configuration) fp32-accurate split-bf16 matrix-core kernels: 1 = 1x1 / "
-                         "transposed convolutions with >= 128 outputs, 2 = also the 3x3 convolutions with >= 192 outputs; the "
-                         "JSON line then says so in `dtype`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,21 +178,13 @@ def main():
         global WINO2D_MIN
         WINO2D_MIN = a.wino2d
         ops.set_option("winograd_2d", a.wino2d)
-    if a.no_materialize:
-        from cwfa_amd import unet as _unet
-        _unet._MATERIALIZE = False
-    if a.no_materialize_up:
-        from cwfa_amd import unet as _unet
-        _unet._MATERIALIZE_UP = False
-    if a.bf16:
-        ops.set_precision("bf16")
-        a.split_bf16 = 2
-    elif a.split_bf16:
-        ops.set_option("split_bf16", a.split_bf16)
+    PREC = {"split": "split_bf16", "fp32": "fp32", "bf16": "bf16"}
+    ops.set_precision(PREC[a.precision])
+    products = {"split": SPLIT_PRODUCTS, "bf16": 1, "fp32": SPLIT_PRODUCTS}[a.precision]
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN
     torch.manual_seed(0)
     np.random.seed(0)
-    conv_inn, cond_nets = CWFA.build_networks(a.depths, a.side, S, with_lrnn=not a.no_lrnn, device=dev)
+    conv_inn, cond_nets = CWFA.build_networks(a.depths, a.side, S, block_type=a.block_type, with_lrnn=not a.no_lrnn, device=dev)
     g = torch.Generator().manual_seed(1 + rank)
     B = a.batch
     cond_input = torch.randn(B, 29, a.side, a.side, generator=g).to(dev)
@@ -184,21 +202,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        fn(); fn()                                           # re-pack affected filter banks, warm up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
     out = step()                                             # cold pass: weight packing, allocator
     assert out.shape == (B, a.depths, a.side, a.side) and bool(torch.isfinite(out).all())
-    # selection pass: which conv kernel/shape dominates?
+    # selection pass: which conv kernels dominate?
     sel = ops.conv_event_sink = ConvEvents()
     step()
     torch.cuda.synchronize()
     tot = sel.totals()
     all_conv_ms = sum(t[0] for t in tot.values())
-    dom = max(tot, key=lambda k: tot[k][0])                  # the kernel (one instantiation) with the largest time share
+    ranked = sorted(tot, key=lambda k: -tot[k][0])
+    dom = ranked[0]                                          # the kernel (one instantiation) with the largest time share
     ops.conv_event_sink = None
     for _ in range(max(a.warmup - 2, 0)):
         step()
 
-    ranked = sorted(tot, key=lambda k: -tot[k][0])
-    sink = ops.conv_event_sink = ConvEvents(only={dom})       # only the dominant kernel carries events in the timed region
+    sink = ops.conv_event_sink = ConvEvents(only={dom})      # only the dominant kernel carries events in the timed region
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -211,84 +238,75 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
-    nll_check = None
-    if world > 1:                                   # the metric's second half: "NLL match vs ref (1/2/4/8 GPU)"
+    # BASELINE.json configs[3] / the metric's second half: forward NLL, batch-sharded, one all-reduce of the NLL sums
+    fwd = None
+    if not a.no_experiment and not a.no_lrnn and a.block_type == "CAT":
         try:
-            nll_check = sharded_nll_check(CWFA, conv_inn[0], a, dev, rank, world)
+            fwd = forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_all, products)
         except Exception as exc:                    # noqa: BLE001  (after the timed region; must not cost the line)
-            nll_check = {"error": repr(exc)[:300]}
+            fwd = {"error": repr(exc)[:300]}
 
     res = None
     if rank == 0:
         t_dom, n_dom, f_dom, shapes = sink.totals()[dom]
-        avg_ms = t_dom / n_dom
-        tf = f_dom / (t_dom * 1e-3) / 1e12
-        alg_bytes = sum(conv_bytes(k) * n for k, n in shapes.items()) / n_dom
+        baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+        dtype = {"split": "f32 (storage, accumulation, wavelets, couplings); convolution products on the bf16 matrix cores from an "
+                          "exact three-way bf16 split of both fp32 operands, six products per fp32 product: fp32-equivalent; "
+                          "plain-fp32-MFMA figure: fp32_mfma",
+                 "fp32": "f32 (v_mfma_f32_32x32x2_f32 / Winograd)",
+                 "bf16": "bf16 conv operands, f32 accumulate, f32 wavelets / couplings (BASELINE.json configs[4]; tolerance restated)"}[a.precision]
         res = {
-            "metric": "volumes/sec inverse-pass @512x512x96 fp32", "value": world * a.steps * B / elapsed,
+            "metric": baseline["metric"], "value": world * a.steps * B / elapsed,
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (conv operands; f32 accumulate, f32 wavelets / couplings)" if a.bf16 else "f32" if not a.split_bf16 else f"f32 (split level {a.split_bf16}: 3-way split bf16 operands, six products, fp32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA (CAT x5 per scale, 64 ch) + "
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA ({a.block_type} blocks, 64 ch) + "
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
                                    f"batch {B}/GPU, random-init weights (BASELINE.json configs[2])",
+                       "precision": a.precision,
                        "parallelism": f"replicated x{world} (independent volumes per GPU, no collective)"},
-            # achieved = algorithmic conv FLOPs (2*Cout*Cin*taps*H*W per launch) of ALL launches of
-            # the dominant kernel inside the timed region / their summed HIP-event durations; avg_launch_ms is the figure
-            # to compare with the rocprofv3 kernel-stats average for the same kernel (profiles/).
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": dom + (" (v_mfma_f32_32x32x16_bf16, six split products per algorithmic FMA)" if "split" in dom else
-                                          " (v_mfma_f32_32x32x2_f32" + (", Winograd: %.2fx the algorithmic MFMA count is issued"
-                                                                         % issued_factor(dom) if "wino" in dom else "") + ")"),
-                         "mfma_issued_frac": tf * issued_factor(dom) / PEAK_FP32_MFMA_TFLOPS,
-                         "shapes": [dict(zip(("ks", "cin", "cout", "H", "W", "B", "launches"), (*k[:6], n)))
-                                    for k, n in sorted(shapes.items(), key=lambda kv: -kv[1])],
-                         "flops_per_launch": f_dom / n_dom, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": avg_ms, "launches_timed": n_dom,
-                         "share_of_conv_time": tot[dom][0] / all_conv_ms, "all_conv_ms_per_step": all_conv_ms},
+            "roofline": roofline_of(dom, t_dom, n_dom, f_dom, shapes, products, tot[dom][0] / all_conv_ms, all_conv_ms),
             "reference_readme": {"volumes_per_s": 6.25, "note": "README.md:29, unstated CUDA GPU, fp16 autocast; not "
                                  "this fp32 metric, hence vs_baseline is null"},
         }
         res["roofline"]["traffic"], res["roofline"]["traffic_detail"] = pmc_traffic(dom, a)
         if len(ranked) > 1:                                        # the runner-up kernel, same definitions, timed in three
             sink2 = ops.conv_event_sink = ConvEvents(only={ranked[1]})   # extra steps AFTER the timed region (its many small
-            for _ in range(3):                                     # launches would otherwise put ~1 % of event gaps into `value`)
+            for _ in range(3):                                     # launches would otherwise put event gaps into `value`)
                 step()
             torch.cuda.synchronize()
             ops.conv_event_sink = None
             t2, n2, f2, sh2 = sink2.totals()[ranked[1]]
-            tf2 = f2 / (t2 * 1e-3) / 1e12
-            tr2, td2 = pmc_traffic(ranked[1], a)
-            res["roofline_second"] = {"bound": "mfma", "achieved": tf2, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": tf2 / PEAK_FP32_MFMA_TFLOPS, "traffic": tr2, "kernel": ranked[1],
-                                      # issued / algorithmic MFMA work: 2/3 for Winograd 3x3; the fused layer = 9 Winograd taps + 1 direct tap of 10
-                                      "mfma_issued_frac": tf2 * issued_factor(ranked[1]) / PEAK_FP32_MFMA_TFLOPS,
-                                      "flops_per_launch": f2 / n2, "avg_launch_ms": t2 / n2, "launches_timed": n2,
-                                      "algorithmic_bytes_per_launch": sum(conv_bytes(k) * n for k, n in sh2.items()) / n2,
-                                      "share_of_conv_time": tot[ranked[1]][0] / all_conv_ms}
-        if nll_check is not None:
-            res["nll_check"] = nll_check
-        res["roofline_dwt"] = dwt_roofline(ops, a, dev)
-        if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
-            try:                                              # never let the side experiment cost the headline line
-                res["experiment_split_bf16"] = split_experiment(ops, step, max(a.steps // 2, 3), B)
-            except Exception as exc:                          # noqa: BLE001
-                res["experiment_split_bf16"] = {"error": repr(exc)[:300]}
-        if world == 1 and not a.split_bf16 and not a.no_lrnn and not a.no_experiment:
-            try:                                              # BASELINE.json configs[4]: bf16 operands in the heavy convolutions
-                res["experiment_bf16"] = bf16_experiment(ops, step, max(a.steps // 2, 3), B)
-            except Exception as exc:                          # noqa: BLE001
-                res["experiment_bf16"] = {"error": repr(exc)[:300]}
+            res["roofline_second"] = roofline_of(ranked[1], t2, n2, f2, sh2, products, tot[ranked[1]][0] / all_conv_ms)
+            res["roofline_second"]["traffic"], _ = pmc_traffic(ranked[1], a)
+        res["roofline_dwt"] = dwt_roofline(ops, step, a, dev)
+        if fwd is not None:
+            res["forward_nll"] = fwd
         if world == 1 and not a.no_lrnn and not a.no_experiment:
+            for name, mode in (("fp32_mfma", "fp32"), ("bf16", "bf16"), ("split", "split")):
+                if mode == a.precision:
+                    continue
+                try:                                          # never let a side measurement cost the headline line
+                    ops.set_precision(PREC[mode])
+                    dt = timed(step, max(a.steps // 2, 3))
+                    res[name] = {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": max(a.steps // 2, 3),
+                                 "note": {"fp32": "the same step on the plain fp32 MFMA kernels (Winograd F(2,3) / F(2x2,3x3)), after the timed region",
+                                          "bf16": "BASELINE.json configs[4]: bf16 conv operands, fp32 accumulation; parity max-rel <= 1e-2, "
+                                                  "L2-rel <= 5e-3 vs the fp32 oracle (tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle)",
+                                          "split": "fp32-equivalent split-bf16 arithmetic (see --precision)"}[mode]}
+                except Exception as exc:                      # noqa: BLE001
+                    res[name] = {"error": repr(exc)[:300]}
+                finally:
+                    ops.set_precision(PREC[a.precision])
             try:
-                res["experiment_train_step"] = train_experiment(conv_inn, cond_nets, dev, a, max(a.steps // 4, 3))
+                res["experiment_train_step"] = train_experiment(conv_inn, cond_nets, dev, a, max(a.steps // 4, 3), ops)
             except Exception as exc:                          # noqa: BLE001
                 res["experiment_train_step"] = {"error": repr(exc)[:300]}
-        if world == 1 and not a.no_cpu_baseline and not a.no_lrnn:
+            finally:
+                ops.set_precision(PREC[a.precision])
+        if world == 1 and not a.no_cpu_baseline and not a.no_lrnn and a.block_type == "CAT":
             try:
-                res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache)
+                res["cpu_baseline"] = cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache, a.cpu_baseline_full)
             except Exception as exc:                          # noqa: BLE001  (host trouble must not lose the GPU measurement)
                 res["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(exc)[:200]}
         print(json.dumps(res), flush=True)
@@ -298,71 +316,87 @@ def main():
     return res
 
 
-def sharded_nll_check(CWFA, g0, a, dev, rank, world):
-    """BASELINE.json configs[3] on the ranks of this run: `world` synthetic volumes (same seed everywhere), rank r takes
-    volume r, the forward / NLL step of the finest flow, ONE all-reduce of the float64[3] shard sums (RCCL over xGMI) --
-    against the same NLL computed by this rank alone over all volumes (no collective).  After the timed region."""
+def forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_all, products, per_gpu=4, steps=5):
+    """BASELINE.json configs[3]: forward NLL of a batch of 512x512x96 volumes over the four flow steps with their condition
+    nets (CWFA.py:966-978), batch sharded over the ranks (4 volumes per GPU: 32 over 8 GPUs), ONE all-reduce of the
+    float64[12] NLL sums per pass (RCCL over xGMI).  After the headline timed region; same barrier / max-over-ranks rule.
+    At N > 1 `nll_check` compares the sharded NLL with the same NLL computed by one rank alone over the first two shards."""
     import torch.distributed as dist
-    gen = torch.Generator().manual_seed(3)
-    D, S = a.depths, a.side
-    x = torch.randn(world, D, S, S, generator=gen).to(dev)
-    c = [torch.randn(world, D // 2, S, S, generator=gen).to(dev), (0.1 * torch.randn(world, D // 2, S, S, generator=gen)).to(dev)]
-    with torch.no_grad():
-        nll, _, _ = CWFA.nll_step(g0, x[rank:rank + 1].contiguous(), [t[rank:rank + 1].contiguous() for t in c])
-        _, logdet, sumsq = CWFA.nll_terms(g0, x, c)
-    ref = (0.5 * float(sumsq[0]) - float(logdet.double().sum()) / world) / (world * x[0].numel())
-    vals = torch.tensor([float(nll)], dtype=torch.float64, device=dev)
-    lo, hi = vals.clone(), vals.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    return {"nll_sharded": float(nll), "nll_single_process": ref, "rel_diff": abs(float(nll) - ref) / abs(ref),
-            "identical_on_all_ranks": bool(float(lo) == float(hi)), "volumes": world, "tolerance": 1e-6}
+    D, Sd = a.depths, a.side
+    nst = len(conv_inn)
+
+    def shard(r):
+        gen = torch.Generator().manual_seed(3 + 7 * r)
+        x = torch.randn(per_gpu, D, Sd, Sd, generator=gen).to(dev)
+        views = torch.randn(per_gpu, 29, Sd, Sd, generator=gen).to(dev)
+        means = [(0.1 * torch.randn(per_gpu, D // 2 ** (n + 1), Sd, Sd, generator=gen)).to(dev) for n in range(nst)]
+        return x, views, means
+
+    x, views, means = shard(rank)
+
+    def one():
+        with torch.no_grad():
+            return CWFA.forward_nll_pass(conv_inn, cond_nets[:nst], x, views, means)
+
+    nll, _ = one()
+    sel = ops.conv_event_sink = ConvEvents()
+    chain = ops.chain_event_sink = []
+    one()
+    torch.cuda.synchronize()
+    ops.conv_event_sink = ops.chain_event_sink = None
+    tot = sel.totals()
+    dom = max(tot, key=lambda k: tot[k][0])
+    chain_ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in chain)
+    chain_bytes = sum(4.0 * 14 * Bc * C * H * W for _, Bc, C, H, W, *_ in chain)   # x (2C) + s,t of 5 blocks (10C) + z, low (2C)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nll, _ = one()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    out = {"value": world * per_gpu * steps / dt, "unit": "volumes/s", "batch_per_gpu": per_gpu, "global_batch": world * per_gpu,
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "scaling": "weak",
+           "workload": f"forward NLL, {Sd}x{Sd}x{D} volumes, four flow steps + condition nets (no LRNN), BASELINE.json configs[3]",
+           "collective": "one all_reduce(SUM) of float64[%d] per pass (nccl = RCCL)" % (3 * nst) if world > 1 else "none (N = 1)",
+           "nll_per_step": [float(v) for v in nll],
+           "roofline": roofline_of(dom, tot[dom][0], tot[dom][1], tot[dom][2], tot[dom][3], products,
+                                   tot[dom][0] / sum(t[0] for t in tot.values())),
+           "chain_fwd": {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "launches": len(chain), "ms": chain_ms}}
+    if world > 1:
+        # the same NLL by ONE process over the volumes of ranks 0 and 1 (no collective) vs the sharded value of a 2-rank
+        # sub-problem is not available here (the all-reduce spans all ranks), so: every rank recomputes the global sums
+        # from all shards sequentially (world x the work, after the timed region) and compares
+        with torch.no_grad():
+            rows = torch.zeros(nst, 3, dtype=torch.float64, device=dev)
+            for r in range(world):
+                xr, vr, mr = shard(r)
+                gt = xr
+                for n, gph in enumerate(conv_inn):
+                    Z, logdet, sumsq = CWFA.nll_terms(gph, gt, [cond_nets[n](vr)[-1], mr[n]])
+                    rows[n] += torch.stack([sumsq[0], logdet.double().sum(), torch.tensor(float(per_gpu), dtype=torch.float64, device=dev)])
+                    gt = Z[1]
+            numel = torch.tensor([float(D * Sd * Sd) / 2 ** n for n in range(nst)], dtype=torch.float64, device=dev)
+            ref = (0.5 * rows[:, 0] - rows[:, 1] / rows[:, 2]) / (rows[:, 2] * numel)
+        rel = float(((nll - ref).abs() / ref.abs()).max())
+        lo, hi = nll.clone(), nll.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["nll_check"] = {"nll_sharded": [float(v) for v in nll], "nll_single_process": [float(v) for v in ref], "max_rel_diff": rel,
+                            "identical_on_all_ranks": bool((lo == hi).all()), "volumes": world * per_gpu, "tolerance": 1e-6}
+    return out
 
 
-def split_experiment(ops, step, steps, batch):
-    """NOT the headline: the same step with the opt-in fp32-accurate split-bf16 matrix-core kernels (level 2: 1x1 /
-    transposed convs and the 3x3 convs with >= 192 outputs), measured after the timed region, for the record."""
-    ops.set_option("split_bf16", 2)
-    try:
-        step(); step()                                       # re-pack the affected filter banks, warm up
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-    finally:
-        ops.set_option("split_bf16", 0)
-    return {"value": batch / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps,
-            "note": "opt-in, not the headline configuration: operands split exactly into three bf16 pieces, six partial "
-                    "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; parity tests hold the fp32 path's bounds "
-                    "(tests/test_gpu_parity.py::test_split_bf16_*)"}
-
-
-def bf16_experiment(ops, step, steps, batch):
-    """NOT the headline (which is fp32): BASELINE.json configs[4], the same step with plain bf16 operands in the heavy
-    convolutions (fp32 accumulation), measured after the timed region."""
-    ops.set_precision("bf16")
-    try:
-        step(); step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-    finally:
-        ops.set_precision("fp32")
-    return {"value": batch / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "dtype": "bf16 operands, f32 accumulate",
-            "note": "configs[4]; parity (max-rel <= 1e-2, L2-rel <= 5e-3 vs the fp32 oracle) in "
-                    "tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle"}
-
-
-def train_experiment(conv_inn, cond_nets, dev, a, steps):
+def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
     """NOT the headline: SURVEY.md 8(f) row 1 -- one training iteration over the WHOLE pyramid on one synthetic volume, in
     the reference's order (CWFA.py:865-1027): LRNN step (L2), then the four flow steps with their condition nets (inverse +
-    forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  After the timed region."""
+    forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  fp32 MFMA kernels."""
     from cwfa_amd import training
+    ops.set_precision("fp32")
     B, D, S = 1, a.depths, a.side
     gen = torch.Generator().manual_seed(17)
     gt = torch.randn(B, D, S, S, generator=gen).to(dev)
@@ -382,12 +416,12 @@ def train_experiment(conv_inn, cond_nets, dev, a, steps):
     n_par = sum(p.numel() for m in list(conv_inn) + list(cond_nets) for p in m.parameters() if p.requires_grad)
     return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps,
             "full_loss_per_pyramid_step": [float(v) for v in res["losses"]], "trainable_parameters": n_par,
-            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; gradients pinned to the reference's autograd "
-                    "by tests/test_gpu_backward.py (fixtures g13-g15)"}
+            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward, fp32 MFMA kernels; gradients pinned to the "
+                    "reference's autograd by tests/test_gpu_backward.py (fixtures g13-g15)"}
 
 
 def pmc_traffic(dom, a):
-    """HBM bytes per launch of the dominant kernel.  FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process
+    """HBM bytes per launch of a kernel.  FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process
     (rocprofv3 --pmc, separate passes); profiles/*_pmc_traffic.json holds the latest such passes over THIS command, averaged
     over the same launches as `achieved`, with the calibration described in DESIGN.md section 6.  (None, None) if the
     committed record does not cover this kernel / workload."""
@@ -402,9 +436,28 @@ def pmc_traffic(dom, a):
     return hit["hbm_bytes_per_launch"], {"source": os.path.basename(files[-1]), **hit}
 
 
-def dwt_roofline(ops, a, dev, reps=20):
-    """The DWT stage on its own: the four inverse depth-Haar levels of one volume (377.5 MB algorithmic at 512x512x96,
-    SURVEY.md 8d: 8 bytes per element read+written), standalone kernels, HIP events on the launch stream."""
+def dwt_roofline(ops, step, a, dev, reps=20):
+    """The DWT stage as it runs IN the path: the inverse depth Haar lives in the fused chain kernel (one launch per flow step:
+    5 gathers + 5 affines + Split/cat + Haar1D^-1).  Algorithmic bytes per launch = (low C + s,t of five blocks 10 C + output
+    2 C) x H x W x 4 B = 13 C HW 4 (z = 0 is never read); HIP events on the launch stream around every chain launch of three
+    steps.  `standalone_haar`: the four inverse Haar levels of one volume as separate haar1d kernels (377.5 MB algorithmic
+    at 512x512x96, SURVEY.md 8d: 8 bytes per element) -- what the north_star's 60 % target was first measured on."""
+    chain = ops.chain_event_sink = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ops.chain_event_sink = None
+    rows = [(kind, B, C, H, W, e0.elapsed_time(e1)) for kind, B, C, H, W, _, _, e0, e1 in chain]
+    ms = sum(r[5] for r in rows)
+    nbytes = sum(4.0 * 13 * B * C * H * W for _, B, C, H, W, _ in rows)
+    big = [r for r in rows if r[2] == max(r2[2] for r2 in rows)]
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+           "kernel": "chain_inv_rows_kernel (in-path: inverse Haar1D + Split/cat + 5 x (gather, affine), one launch per flow step)",
+           "bytes_per_volume": nbytes / 3 / a.batch, "us_per_volume": 1e3 * ms / 3 / a.batch, "launches_timed": len(rows),
+           "largest_level": {"bytes_per_launch": 4.0 * 13 * big[0][1] * big[0][2] * big[0][3] * big[0][4],
+                             "avg_launch_us": 1e3 * sum(r[5] for r in big) / len(big),
+                             "GBps": 4.0 * 13 * big[0][1] * big[0][2] * big[0][3] * big[0][4] / (sum(r[5] for r in big) / len(big) * 1e-3) / 1e9}}
     levels = [a.depths // 2 ** n for n in range(4)]
     bufs = [torch.randn(1, d, a.side, a.side, device=dev) for d in levels]
     for b in bufs:
@@ -417,28 +470,34 @@ def dwt_roofline(ops, a, dev, reps=20):
             ops.haar1d(b, True)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    nbytes = sum(8.0 * b.numel() for b in bufs)
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    # the largest level alone (per-launch figure for the rocprof cross-check)
-    e0.record()
-    for _ in range(reps):
-        ops.haar1d(bufs[0], True)
-    e1.record()
-    torch.cuda.synchronize()
-    ms0 = e0.elapsed_time(e1) / reps
-    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": None, "kernel": "haar1d_inv_kernel<4>", "bytes_per_volume": nbytes, "us_per_volume": 1e3 * ms,
-            "largest_level": {"bytes_per_launch": 8.0 * bufs[0].numel(), "avg_launch_us": 1e3 * ms0,
-                              "GBps": 8.0 * bufs[0].numel() / (ms0 * 1e-3) / 1e9}}
+    ms2 = e0.elapsed_time(e1) / reps
+    nb2 = sum(8.0 * b.numel() for b in bufs)
+    out["standalone_haar"] = {"kernel": "haar1d_inv_kernel<4> (NOT launched by the path)", "achieved": nb2 / (ms2 * 1e-3) / 1e9, "unit": "GB/s",
+                              "frac": nb2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_volume": nb2, "us_per_volume": 1e3 * ms2}
+    return out
 
 
-def cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache):
-    """The CPU oracle (oracle/cwfa_oracle.py, a port of the reference's op sequence onto torch CPU ops) on the same
-    weights and inputs: ONE full 512x512x96 volume, all host cores PyTorch gives us."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache, full=False):
+    """The CPU oracle (oracle/cwfa_oracle.py, a port of the reference's op sequence onto torch CPU ops) on the same weights and
+    inputs, timed per stage (LRNN, then per flow step its condition net and its inverse) on one full 512x512x96 volume.
+    Default (bounded: ~20 s of CPU work): one warm-up of the coarsest flow step (threads, oneDNN primitives), then ONE timed
+    full volume with torch threads = all host cores.  (The sample cannot be a spatial crop: the row / column permutations of
+    the flow steps are tables of length 512.)
+    `--cpu-baseline-full`: the SURVEY.md 8d protocol -- one full warm-up, median of three full volumes, with torch threads =
+    all host cores AND = 8 (the reference's default, main.py:75); several minutes.  Its latest result on the GPU box is kept
+    in profiles/*_cpu_baseline_full.json and attached to the default line as `protocol_full`."""
     from oracle import cwfa_oracle as O
-    cores = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(cores)
+    ncores = min(os.cpu_count() or 1, 64)
     cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
     steps = []
     for n, g in enumerate(conv_inn):
@@ -447,14 +506,52 @@ def cpu_baseline(conv_inn, cond_nets, cond_input, mean_cache):
     lrnn_sd = cpu(cond_nets[-1].state_dict())
     ci = cond_input[:1].cpu()
     mc = [m[:1].cpu() for m in mean_cache]
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        vols = O.inverse_pass(steps, None, ci, mc, lrnn_sd=lrnn_sd, lrnn_train=True)
-    dt = time.perf_counter() - t0
-    assert vols[-1].shape[1] == conv_inn[0].dims_in[0][0]
-    return {"value": 1.0 / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full volume (LRNN + 4 flow steps + condition nets), single cold run, {dt:.1f} s, "
-                      f"torch {torch.__version__} CPU fp32"}
+
+    def flow(n, up):
+        t0 = time.perf_counter()
+        om = O.omega_net(steps[n]["omega"], ci)
+        t1 = time.perf_counter()
+        up, _ = O.flow_step(steps[n]["inn"], (torch.zeros_like(up), up), [om, mc[n]], True, steps[n]["axes"])
+        return up, t1 - t0, time.perf_counter() - t1
+
+    def run_once():
+        t = {}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            up = O.lrnn(lrnn_sd, ci, mc[-1], train=True)
+            t["lrnn"] = time.perf_counter() - t0
+            for n in range(len(steps) - 1, -1, -1):
+                up, t[f"omega{n}"], t[f"flow{n}"] = flow(n, up)
+        t["total"] = sum(t.values())
+        return t
+
+    def protocol(threads, runs, warm_full):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            if warm_full:
+                run_once()
+            else:
+                flow(len(steps) - 1, torch.zeros(1, mc[-1].shape[1], ci.shape[2], ci.shape[3]))
+        ts = [run_once() for _ in range(runs)]
+        med = {k: float(np.median([t[k] for t in ts])) for k in ts[0]}
+        return {"threads": torch.get_num_threads(), "runs": runs, "seconds_per_volume": med["total"], "value": 1.0 / med["total"],
+                "stages_s": {k: round(v, 3) for k, v in med.items() if k != "total"}}
+
+    alln = protocol(ncores, 3 if full else 1, full)
+    out = {"value": alln["value"], "unit": "volumes/s", "cores": alln["threads"], "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"1 full volume (LRNN + 4 flow steps + condition nets), " +
+                     (f"one full warm-up then median of {alln['runs']} runs" if full else "one timed run after a warm-up of the coarsest flow step") +
+                     f", {alln['seconds_per_volume']:.1f} s per volume, torch {torch.__version__} CPU fp32",
+           "stages_s": alln["stages_s"]}
+    if full:
+        out["threads_8"] = protocol(8, 3, True)
+        torch.set_num_threads(ncores)
+    else:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_baseline_full.json")))
+        if files:
+            out["protocol_full"] = {"source": os.path.basename(files[-1]), **json.load(open(files[-1]))}
+    return out
 
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@ import torch
 from . import ops
 
 __all__ = ["sample_z_truncated", "check_empty_depths", "evaluate_INN_forward", "inverse_pass", "nll_step",
-           "nll_terms", "allreduce_nll", "build_networks", "step_log_likelihoods", "allgather_scores", "detect_ood"]
+           "nll_terms", "allreduce_nll", "build_networks", "step_log_likelihoods", "allgather_scores", "detect_ood",
+           "forward_nll_pass"]
 
 
 def _no_grad_trunc_normal_(tensor, mean=0., std=1., a=-1., b=1.):
@@ -204,6 +205,28 @@ def nll_step(graph, x, c, group=None):
     numel_total = terms[2] * x[0].numel()      # `upsampled_vol.numel()`: the step's whole input volume (CWFA.py:911,978)
     nll = (0.5 * terms[0] - terms[1] / terms[2]) / numel_total
     return nll, Z, logdet
+
+
+def forward_nll_pass(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache, group=None):
+    """The forward / NLL twin of ``inverse_pass`` over the whole pyramid for one (shard of a) batch -- BASELINE.json
+    configs[3]: for n = 0 .. S-2: condition net Omega_n, ``Z, logdet = conv_inn[n](gt_n, c=[Omega_n(views), mean_n])``
+    (CWFA.py:895-899,966), ``gt_{n+1} = Z[1]`` (the low band: what CWFA.py:821 caches), and
+    ``NLL_n = (0.5 * ||Z0||^2 - mean_b logdet) / numel(batch volume)`` (CWFA.py:970-978) with the norm and the mean
+    taken over the GLOBAL batch.  With a process group the S-1 triples {sum z^2, sum logdet, B_local} are summed over
+    the ranks in ONE all-reduce of a float64[3(S-1)] vector (RCCL over xGMI on MI355X) and every rank returns the same
+    values.  Returns (nll float64[S-1], low-resolution volume gt_{S-1})."""
+    gt = gt_volume
+    rows = []
+    for n, g in enumerate(conv_inn):
+        Z, logdet, sumsq = nll_terms(g, gt, [cond_nets[n](cond_input)[-1], mean_vols_cache[n]])
+        rows.append(torch.stack([sumsq[0], logdet.to(torch.float64).sum(),
+                                 torch.tensor(float(gt.shape[0]), dtype=torch.float64, device=gt.device)]))
+        gt = Z[1]
+    terms = allreduce_nll(torch.stack(rows).reshape(-1), group).view(len(conv_inn), 3)
+    numel = torch.tensor([float(gt_volume[0].numel()) / 2 ** n for n in range(len(conv_inn))], dtype=torch.float64,
+                         device=gt_volume.device)                    # per-sample numel of the step's input volume
+    nll = (0.5 * terms[:, 0] - terms[:, 1] / terms[:, 2]) / (terms[:, 2] * numel)
+    return nll, gt
 
 
 def allreduce_nll(terms, group=None):

@@ -196,8 +196,15 @@ def chain_inv(z, low, stages, logdet=None):
             raise ValueError(f"z {tuple(z.shape)} and low {tuple(low.shape)} differ")
     ch, keep = _chain(stages)
     out = torch.empty((B, 2 * Cc, H, W), dtype=torch.float32, device=low.device)
+    rec = chain_event_sink
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.cwfa_chain_inv_f32(_p(z), _p(low), _p(out), C.byref(ch), B, Cc, H, W, zbs, lbs, 2 * Cc * H * W, _p(logdet),
                                _stream()), "chain_inv")
+    if rec is not None:
+        e1.record()
+        rec.append(("inv", B, Cc, H, W, len(stages), z is not None, e0, e1))
     return out
 
 
@@ -210,9 +217,19 @@ def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
     ch, keep = _chain(stages)
     low = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
     z = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    rec = chain_event_sink
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.cwfa_chain_fwd_f32(_p(x), _p(low), _p(z), C.byref(ch), _p(_idx(final_perm)), B, Cc, H, W, xbs, Cc * H * W,
                                Cc * H * W, _p(logdet), _p(sumsq), _stream()), "chain_fwd")
+    if rec is not None:
+        e1.record()
+        rec.append(("fwd", B, Cc, H, W, len(stages), True, e0, e1))
     return z, low
+
+
+chain_event_sink = None     # list collecting (direction, B, C, H, W, stages, z_read, start_event, end_event); set by bench.py only
 
 
 def _chain_grads(grads, shape):

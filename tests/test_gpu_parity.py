@@ -676,11 +676,22 @@ def test_full_config3_inverse_vs_oracle():
         ref = O.inverse_pass(steps, None, cond_input, mean_cache, lrnn_sd=cpu(enc.state_dict()), lrnn_train=True)[-1]
     assert out.shape == (1, 96, 512, 512)
     assert_close(out, ref, TOL, "full-size config-3 inverse")
+    from cwfa_amd import ops
+    from conftest import rel_err
+    # bench.py's headline precision: every heavy convolution (incl. the 64-channel fused layers, both convs) from an exact
+    # three-way bf16 split of both operands, six products, fp32 accumulation -- held to the SAME fp32 bound (1e-4)
+    ops.set_precision("split_bf16")
+    try:
+        with torch.no_grad():
+            outs = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    assert_close(outs, ref, TOL, "full-size config-3 inverse, split-bf16 (fp32-equivalent) precision")
+    assert float((outs - out).abs().max()) > 0.0, "the split mode must actually run the split kernels"
     # BASELINE.json configs[4]: the same inverse with bf16 operands in the heavy convolutions (fp32 accumulation; wavelets,
     # couplings, permutations in fp32).  Tolerance re-stated for bf16 as SURVEY.md 8(d) measured on the reference's own
     # CPU autocast: max|d|/max|ref| <= 1e-2 and L2-relative <= 5e-3 against the fp32 oracle.
-    from cwfa_amd import ops
-    from conftest import rel_err
     ops.set_precision("bf16")
     try:
         with torch.no_grad():
@@ -720,6 +731,46 @@ def test_full_size_forward_nll_vs_oracle():
     ss, sl, B = O.nll_terms(zr, ldr)
     ref = O.nll_from_terms(ss, sl, B, x.numel())
     assert abs(float(nll) - ref) <= 1e-5 * abs(ref)
+
+
+def test_config4_forward_nll_pass_batch4_vs_oracle():
+    """BASELINE.json configs[3] at its per-GPU shape: batch 4 of 512x512x96 volumes, the forward / NLL pass over ALL four
+    flow steps with their condition nets (``CWFA.forward_nll_pass``: what bench.py's forward_nll leg times) against the CPU
+    oracle step by step: latent, low band (the next level's input), log-det and the NLL of CWFA.py:978.  ~1-2 min of CPU."""
+    from cwfa_amd import CWFA
+    from oracle import cwfa_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    B = 4
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 5, with_lrnn=False, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 96, 512, 512, generator=g)
+    views = torch.randn(B, 29, 512, 512, generator=g)
+    means = [0.1 * torch.randn(B, 96 // 2 ** (n + 1), 512, 512, generator=g) for n in range(4)]
+    xg, vg, mg = x.cuda(), views.cuda(), [m.cuda() for m in means]
+    with torch.no_grad():
+        nll, low = CWFA.forward_nll_pass(conv_inn, cond_nets, xg, vg, mg)
+        per_step = []
+        gt = xg
+        for n, gi in enumerate(conv_inn):
+            Z, logdet, _ = CWFA.nll_terms(gi, gt, [cond_nets[n](vg)[-1], mg[n]])
+            per_step.append((Z[0].cpu(), Z[1].cpu(), logdet.cpu()))
+            gt = Z[1]
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    gt = x
+    for n, gi in enumerate(conv_inn):
+        axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+        with torch.no_grad():
+            om = O.omega_net(cpu(cond_nets[n].state_dict()), views)
+            (zr, lowr), ldr = O.flow_step(cpu(gi.state_dict()), gt, [om, means[n]], False, axes)
+        assert_close(per_step[n][0], zr, TOL, f"latent, step {n}")
+        assert_close(per_step[n][1], lowr, 5e-6, f"low band, step {n}")
+        assert_close(per_step[n][2], ldr, TOL, f"log-det, step {n}")
+        ss, sl, Bn = O.nll_terms(zr, ldr)
+        ref = O.nll_from_terms(ss, sl, Bn, gt.numel())
+        assert abs(float(nll[n]) - ref) <= 1e-5 * abs(ref), (n, float(nll[n]), ref)
+        gt = lowr
+    assert_close(low, gt, 1e-5, "lowest-resolution volume")
 
 
 @pytest.mark.parametrize("cfg", [(1, 70, 16, 32, 200), (2, 33, 9, 37, 130), (1, 256, 24, 64, 512)])
