@@ -375,6 +375,9 @@ def _lower_cat_step(g: "GraphINN"):
     haar, split = inner[0], inner[1]
     if type(haar.module).__name__ != "HaarTransform1D" or type(split.module).__name__ != "Split":
         return None
+    if getattr(haar.module, "jac_fwd", 0.0) != 0.0 or getattr(haar.module, "jac_rev", 0.0) != 0.0:
+        return None                 # rebalance != 1: the Haar node contributes ndims*log(rebalance) to the log-det
+        #                             (INN_utils.py:133-157) which the fused chain does not carry -> generic node walk
     if haar.inputs[0][0] is not g.in_nodes[0] or split.inputs[0][0] is not haar or len(split.output_dims) != 2:
         return None
     if getattr(split.module, "dim", None) != 0 or split.output_dims[0] != split.output_dims[1]:

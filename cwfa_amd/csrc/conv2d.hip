@@ -1079,7 +1079,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
             constexpr int ntap = (tap + 1) % 9, ndy = ntap / 3, ndx = ntap % 3;
             int nb = wbuf + 2;
             nb = nb >= 3 ? nb - 3 : nb;
-#ifndef CWFA_EXP_SPLIT_NODMA
             dma_w(step + 2, nb);
             if constexpr (!FUSED) {
                 if constexpr (tap < 4) dma_x(tap, chunk + 1, (chunk + 1) & 1);  // next chunk's input tile, one item per step
@@ -1091,7 +1090,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
                 if constexpr (tap == 6) store_entry(sc_int<0>{}, chunk + 1, (chunk + 1) & 1);
                 if constexpr (tap == 7) store_entry(sc_int<1>{}, chunk + 1, (chunk + 1) & 1);
             }
-#endif
             int w1 = wbuf + 1;
             w1 = w1 == 3 ? 0 : w1;
 #pragma unroll
@@ -1107,7 +1105,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
                 }
                 if (n == 2) {
                     // weight slice step+1 (issued one step ago) has landed everywhere; this step's own DMAs may stay in flight
-#ifndef CWFA_EXP_SPLIT_NODMA
                     // allowed in flight: this step's own loads (3 weight DMAs + its input items)
                     if constexpr (!FUSED) {
                         if constexpr (tap < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1119,10 +1116,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
                     } else {
                         asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                     }
-#endif
-#ifndef CWFA_EXP_SPLIT_NOBAR
                     __builtin_amdgcn_s_barrier();
-#endif
                     load_a(sc_int<set ^ 1>{}, w1);
                 }
 #pragma unroll

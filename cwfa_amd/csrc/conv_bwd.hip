@@ -149,11 +149,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
     __syncthreads();
     for (; strip < p.nstrips; strip += gridDim.x) {
         const int next = strip + gridDim.x;
-#ifdef CWFA_EXP_WG_NOSTAGE
-        const bool more = false;
-#else
         const bool more = next < p.nstrips;
-#endif
         if (more) issue(next);
         const float* xs = smem + buf * C::BUFW + kh * WG_CHP + cit * 32 + l31;
         const float* ds = smem + buf * C::BUFW + C::XW + kh * WG_CHP + mt * 32 + l31;
@@ -163,50 +159,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgParams p) {
         auto fetch = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int row = s / 16, col = (2 * s) % 32;
-#ifdef CWFA_EXP_WG_NOLDS
-            av[s & 1] = (float)(s + lane);
-#pragma unroll
-            for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = (float)(i + s);
-#else
             av[s & 1] = ds[(2 * s) * WG_CHP];
 #pragma unroll
             for (int i = 0; i < C::TAPS; ++i) bv[s & 1][i] = xs[((row + i / KW) * C::XC + col + i % KW) * WG_CHP];
-#endif
         };
         fetch(std::integral_constant<int, 0>{});
         static_for<32>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-#ifdef CWFA_EXP_WG_BURST
-            if constexpr (s + 1 < 32) fetch(std::integral_constant<int, s + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < C::TAPS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][i], acc[i], 0, 0, 0);
-            bacc += av[s & 1];
-            __builtin_amdgcn_sched_barrier(0);
-#else
             // one operand read of step s + 1 after every MFMA of step s: a burst of reads between two steps would hold the
             // issue port longer than the last MFMA keeps the matrix pipe busy
             constexpr int s1 = s + 1, row1 = s1 / 16, col1 = (2 * s1) % 32;
 #pragma unroll
             for (int i = 0; i < C::TAPS; ++i) {
-#ifdef CWFA_EXP_WG_NOMFMA
-                acc[i][0] += av[s & 1] * bv[s & 1][i];
-#else
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][i], acc[i], 0, 0, 0);
-#endif
                 if constexpr (s1 < 32) {
-#ifdef CWFA_EXP_WG_NOLDS
-                    bv[s1 & 1][i] = (float)(i + s1);
-                    if (i == 0) av[s1 & 1] = (float)(s1 + lane);
-#else
                     bv[s1 & 1][i] = xs[((row1 + i / KW) * C::XC + col1 + i % KW) * WG_CHP];
                     if (i == 0) av[s1 & 1] = ds[(2 * s1) * WG_CHP];
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             bacc += av[s & 1];
-#endif
         });
         if (more) stash(buf ^ 1);
         __syncthreads();

@@ -72,12 +72,7 @@ struct WParams {
     int64_t hidden_bs;
 };
 
-#ifdef CWFA_EXP_STAMP
-__device__ long long g_stamps[8 * 40 * 10 + 64];
-#define LSTAMP(k) do { if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_stamps[8 * 40 * 10 + (threadIdx.x >> 6) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
 #define LSTAMP(k)
-#endif
 
 struct WTile {
     int wm, wn, kh, l31, ct, b, row0, col0;
@@ -278,12 +273,7 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
             aq[slot][0] = *ua;
         }
     };
-#ifdef CWFA_EXP_STAMP
-    const bool stamp_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0;
-#define STAMP(k) do { if (stamp_on && chunk < 40) g_stamps[((threadIdx.x >> 6) * 40 + chunk) * 10 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
 #define STAMP(k)
-#endif
     // MORE / PF (is there a chunk c+1 to store, a chunk c+2 to load) are compile-time: the steady-state body carries no
     // branches, the last two chunks run their own copies
     auto mfmas = [&](int cur, int chunk, auto morec, auto pfc) {
@@ -304,13 +294,11 @@ __device__ __forceinline__ void wino_mainloop(const WParams& p, const WTile& t, 
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
                 acc[m][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % (DEPTH + 1)][m], bq[s % (DEPTH + 1)], acc[m][xi], 0, 0, 0);
-#ifndef CWFA_EXP_NOSTAGE
             if constexpr (s >= SLOT0 && (s - SLOT0) % SLOTD == 0 && (s - SLOT0) / SLOTD < NITEM) {
                 constexpr int k = (s - SLOT0) / SLOTD;
                 if constexpr (more) store_item(sc_int<k>{}, cur ^ 1);
                 if constexpr (pf) load_item(sc_int<k>{}, chunk + 2);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -737,8 +725,3 @@ int cwfa_wino_layer(const float* x, const float* w3_packed, const float* b3, con
     return CWFA_OK;
 }
 
-#ifdef CWFA_EXP_STAMP
-extern "C" int cwfa_debug_stamps(long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
-}
-#endif

@@ -214,16 +214,8 @@ __global__ __launch_bounds__(W2::NTHREADS) void conv3x3_wino2d_kernel(W2Params p
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-#ifdef CWFA_EXP_NOXFORM
-                const f32x4 q = {dr[xi][j], dr[xi][j + 1], dr[xi][j + 2], dr[xi][j + 3]};
-#else
                 const f32x4 q = {v[2 * j][xi], v[2 * j + 1][xi], v[4 + 2 * j][xi], v[4 + 2 * j + 1][xi]};
-#endif
-#ifdef CWFA_EXP_NOWRITE
-                asm volatile("" : : "v"(q));
-#else
                 *reinterpret_cast<f32x4*>(dst + (2 * xi + j) * (C::CK * 2 * 32 * 2)) = q;
-#endif
             }
     };
     const unsigned uoff = tid * 16;
@@ -268,20 +260,16 @@ __global__ __launch_bounds__(W2::NTHREADS) void conv3x3_wino2d_kernel(W2Params p
             }
             acc[2 * cp] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % RING][0], bq[s % RING][0], acc[2 * cp], 0, 0, 0);
             acc[2 * cp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s % RING][1], bq[s % RING][1], acc[2 * cp + 1], 0, 0, 0);
-#ifndef CWFA_EXP_NOSTAGE
             if constexpr (more && s >= SLOT0 && (s - SLOT0) % SLOTD == 0 && (s - SLOT0) / SLOTD < NITEM) {
                 constexpr int k = (s - SLOT0) / SLOTD;
                 if constexpr (k == 0) {
                     store_v(sc_int<set ^ 1>{}, cur ^ 1);
-#ifndef CWFA_EXP_NOVLOAD
                     load_v(sc_int<set ^ 1>{}, chunk + 3);      // past the last chunk: out of range, reads zeros, never stored
-#endif
                 } else {
                     store_u(k - 1, cur ^ 1);
                     load_u(k - 1, chunk + 2);
                 }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };

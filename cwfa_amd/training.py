@@ -243,19 +243,23 @@ def step_backward(graph, gt, c, low=None, z=None, cond_weight=0.40984, loss_func
 
 
 class _CondTape:
-    __slots__ = ("block", "x", "o1", "o")
+    __slots__ = ("block", "x", "o1", "o", "drop_mask")
 
-    def __init__(self, block, x, o1, o):
-        self.block, self.x, self.o1, self.o = block, x, o1, o
+    def __init__(self, block, x, o1, o, drop_mask=None):
+        self.block, self.x, self.o1, self.o, self.drop_mask = block, x, o1, o, drop_mask
 
 
-def cond_forward_train(cond_net, views):
-    """``cond_network.forward`` (networks.py:165-242, eval mode as CWFA.py:527-528 keeps the flow steps' condition nets:
-    Dropout3d off) with the two 2-D maps the backward needs kept.  Returns (omega, tape)."""
+def cond_forward_train(cond_net, views, drop_mask=None):
+    """``cond_network.forward`` (networks.py:165-242) with the two 2-D maps the backward needs kept.  Returns (omega, tape).
+
+    Mode: the reference builds the flow steps' condition nets in eval mode (CWFA.py:527-528) but switches the OPTIMISED
+    step's net to train mode (``cond_nets[steps_to_optimize[0]].train()``, CWFA.py:768,859), so its ``Dropout3d(p=0.5)`` on
+    the hidden Conv3d channels is live (networks.py:224).  Here: if the block is in train mode a keep / scale table
+    ``drop_mask`` [B, K] (entries 0 or 1/(1-p)) is drawn from torch's RNG (or taken from the argument: fixtures pin a fixed
+    mask).  Dropout3d zeroes whole hidden channels per sample and the second Conv3d is linear in them, so the mask is
+    FOLDED INTO THAT CONV'S WEIGHTS per sample, w2[b, k] = mask[b, k] * w2[k]: the fused 1 -> K -> 1 kernel and its backward
+    run unchanged, one launch per sample."""
     blk = cond_net.subnetworks[0]
-    if blk.training:
-        raise NotImplementedError("cond_forward_train: train-mode Dropout3d is not on the HIP path (the reference keeps the "
-                                  "flow steps' condition nets in eval mode, CWFA.py:527-528)")
     a = blk.relu.weight
     P = blk._packed.get
     c1, c2, ds = blk.conv1[0], blk.conv2[0], blk.downsample[0]
@@ -263,8 +267,26 @@ def cond_forward_train(cond_net, views):
     r = ops.conv2d(views, P(ds), bias=ds.bias)
     o = ops.conv2d(o1, P(c2), bias=c2.bias, residual=r, act2="prelu", prelu_alpha=a)
     k1, k2 = blk.conv3d[0], blk.conv3d[3]
-    omega = ops.conv3d_1k1(o, k1.weight, k1.bias, a, k2.weight, k2.bias)
-    return omega, _CondTape(blk, views, o1, o)
+    if drop_mask is None and blk.training:
+        p_drop = float(getattr(blk.conv3d[2], "p", 0.0))
+        K = k1.weight.shape[0]
+        if p_drop > 0.0:
+            keep = (torch.rand(o.shape[0], K, device=o.device) >= p_drop).to(torch.float32)
+            drop_mask = keep / (1.0 - p_drop)
+    if drop_mask is None:
+        omega = ops.conv3d_1k1(o, k1.weight, k1.bias, a, k2.weight, k2.bias)
+    else:
+        drop_mask = drop_mask.to(device=o.device, dtype=torch.float32)
+        if tuple(drop_mask.shape) != (o.shape[0], k1.weight.shape[0]):
+            raise ValueError(f"cond_forward_train: drop_mask must be [B, K] = {(o.shape[0], k1.weight.shape[0])}")
+        omega = torch.cat([ops.conv3d_1k1(o[b:b + 1], k1.weight, k1.bias, a, _masked_w2(k2.weight, drop_mask[b]), k2.bias)
+                           for b in range(o.shape[0])], 0)
+    return omega, _CondTape(blk, views, o1, o, drop_mask)
+
+
+def _masked_w2(w2, mask_b):
+    """Conv3d(K -> 1) weight [1, K, 3, 3, 3] with hidden channel k scaled by mask_b[k]."""
+    return (w2.detach() * mask_b.view(1, -1, 1, 1, 1)).contiguous()
 
 
 def _acc(param, g):
@@ -285,7 +307,15 @@ def cond_backward(tape, g_omega):
         raise NotImplementedError("cond_backward: PReLU slope <= 0 (pre-activations are recovered from the layer outputs)")
     c1, c2, ds = blk.conv1[0], blk.conv2[0], blk.downsample[0]
     k1, k2 = blk.conv3d[0], blk.conv3d[3]
-    g_o, dW1, db1, dW2, db2, dalpha = ops.conv3d_1k1_backward(tape.o, g_omega, k1.weight, k1.bias, a, k2.weight)
+    if tape.drop_mask is None:
+        g_o, dW1, db1, dW2, db2, dalpha = ops.conv3d_1k1_backward(tape.o, g_omega, k1.weight, k1.bias, a, k2.weight)
+    else:            # per sample with the masked second-conv weights; d/dw2[k] = mask[b, k] * d/d(masked weight)
+        parts = [ops.conv3d_1k1_backward(tape.o[b:b + 1], g_omega[b:b + 1], k1.weight, k1.bias, a, _masked_w2(k2.weight, tape.drop_mask[b]))
+                 for b in range(tape.o.shape[0])]
+        g_o = torch.cat([p_[0] for p_ in parts], 0)
+        dW1, db1 = sum(p_[1] for p_ in parts), sum(p_[2] for p_ in parts)
+        dW2 = sum(p_[3] * tape.drop_mask[b].view(1, -1, 1, 1, 1).to(p_[3].dtype) for b, p_ in enumerate(parts))
+        db2, dalpha = sum(p_[4] for p_ in parts), sum(p_[5] for p_ in parts)
     _acc(k1.weight, dW1)
     _acc(k1.bias, db1)
     _acc(k2.weight, dW2)
@@ -310,6 +340,10 @@ def _prelu_of(act):
     import torch.nn as nn
     if not isinstance(act, nn.PReLU) or act.weight.numel() != 1:
         raise NotImplementedError("UNet backward: single-parameter PReLU activations only (what the LRNN builds)")
+    if not float(act.weight.detach()) > 0.0:
+        # the backward kernels recover the pre-activation sign from the layer OUTPUT and form d(alpha) as g*y/alpha
+        # (conv_bwd.hip: bn_act_bwd / prelu_bwd): a slope <= 0 would give silently wrong gradients or NaN
+        raise NotImplementedError("UNet backward: PReLU slope <= 0 (pre-activations are recovered from the layer outputs)")
     return act.weight
 
 
@@ -543,7 +577,8 @@ def lrnn_step_backward(encoder, views, mean_vol, gt, loss_func="L2", group=None)
 
 
 def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache, optimizers=None, lr=None, cond_weight=0.40984,
-                    loss_func_reg="L2", loss_func_first_step="L2", z_sampler=None, use_mean_branch=True, group=None):
+                    loss_func_reg="L2", loss_func_first_step="L2", z_sampler=None, use_mean_branch=True, group=None,
+                    views_noise_std=0.0, cond_dropout=False):
     """One training iteration over the whole pyramid for one batch, in the order of the reference's loop (CWFA.py:865-1027):
     the last step first -- LRNN on the views (+ mean-volume branch), L2 loss against the coarsest level of the ground-truth
     pyramid -- then every flow step from coarse to fine: condition net, inverse pass from the (detached) previous
@@ -554,6 +589,10 @@ def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache,
     step n = 0..S-1: a torch optimiser over that step's parameters, or a pair (flow optimiser, condition-net optimiser)
     as the reference keeps them (``optimizer`` / ``optimizer_cond``).  ``z_sampler(shape) -> tensor`` draws the latent of the
     inverse pass (None: z = 0, the reference's default temperature, main.py:109).
+    The reference's two regularisers of this loop, both OFF by default here so that a call is deterministic (they draw from
+    torch's RNG): ``views_noise_std`` -- N(0, std) noise added to the views of the LRNN step (CWFA.py:881 uses std 0.5 when
+    ``--add_noise 1``, main.py:46's default); ``cond_dropout`` -- the optimised step's condition net in train mode, i.e.
+    Dropout3d(0.5) on its hidden Conv3d channels (CWFA.py:768,859; networks.py:224), see ``cond_forward_train``.
     Returns {"losses": per-step full_loss (index = pyramid step), "nll": ..., "recon": ..., "volume": finest reconstruction}."""
     S = len(conv_inn) + 1
     gt_cache = [gt_volume]
@@ -582,7 +621,10 @@ def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache,
     enc = cond_nets[S - 1]
     for p in params_of([enc]):
         p.grad = None
-    loss, up = lrnn_step_backward(enc, cond_input, mean_vols_cache[S - 2] if use_mean_branch else None, gt_cache[S - 1],
+    views_lrnn = cond_input
+    if views_noise_std:                                      # CWFA.py:881: torch.normal(0, 0.5, cond_input.size())
+        views_lrnn = ops.axpby(cond_input, 1.0, torch.randn_like(cond_input), float(views_noise_std))
+    loss, up = lrnn_step_backward(enc, views_lrnn, mean_vols_cache[S - 2] if use_mean_branch else None, gt_cache[S - 1],
                                   loss_func=loss_func_first_step, group=group)
     losses[S - 1] = recons[S - 1] = loss
     update(S - 1, [enc])
@@ -590,7 +632,13 @@ def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache,
         g, cn = conv_inn[n], cond_nets[n]
         for p in params_of([g, cn]):
             p.grad = None
-        omega, ctape = cond_forward_train(cn, cond_input)
+        was_training = cn.training
+        if cond_dropout:
+            cn.train()                                       # CWFA.py:859
+        try:
+            omega, ctape = cond_forward_train(cn, cond_input)
+        finally:
+            cn.train(was_training)
         z = None if z_sampler is None else z_sampler((up.shape[0],) + tuple(g.global_out_shapes[0]))
         out = step_backward(g, gt_cache[n], [omega, mean_vols_cache[n]], low=up, z=z, cond_weight=cond_weight,
                             loss_func=loss_func_reg, group=group, want_cond_grads=True)

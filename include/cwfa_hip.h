@@ -35,8 +35,7 @@ enum {
     CWFA_E_INVAL = -1,  /* null pointer / bad enum / negative size */
     CWFA_E_SHAPE = -2,  /* shape not supported by the kernel */
     CWFA_E_ALIGN = -3,  /* pointer / stride alignment */
-    CWFA_E_HIP = -4,    /* HIP runtime error at launch */
-    CWFA_E_RCCL = -5
+    CWFA_E_HIP = -4     /* HIP runtime error at launch */
 };
 
 /* soft-clamp of the multiplicative coupling coefficient: s = clamp * f(a)

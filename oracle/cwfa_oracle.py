@@ -413,6 +413,24 @@ def flow_step(sd: SD, inputs, c: Sequence[Tensor], rev: bool, axes: Dict[int, in
     return x, jac
 
 
+# --------------------------------------------------------------------------- graph topology / fixed 1x1
+def concat(xs: Sequence[Tensor], rev_input: Optional[Tensor] = None, sizes: Optional[Sequence[int]] = None):
+    """Concat along the channel axis: fwd ``torch.cat`` (graph_topology.py:136-143), rev ``torch.split`` into ``sizes``;
+    log-det 0."""
+    if rev_input is not None:
+        return list(torch.split(rev_input, list(sizes), dim=1)), 0
+    return torch.cat(list(xs), dim=1), 0
+
+
+def fixed1x1conv(M: Tensor, x: Tensor, rev: bool) -> Tuple[Tensor, float]:
+    """Fixed1x1Conv (fixed_transforms.py:95-133): fwd ``conv2d(x, M^T[...,None,None])``, rev with (M^T)^-1;
+    log-det = +-log|det M| * H*W."""
+    w = M.t().inverse() if rev else M.t()
+    n_pix = x.shape[2] * x.shape[3]
+    j = float(torch.slogdet(M)[1]) * n_pix
+    return F.conv2d(x, w.reshape(*M.shape, 1, 1)), (-j if rev else j)
+
+
 # --------------------------------------------------------------------------- pipelines
 def pyramid_forward(x: Tensor, n_steps: int) -> List[Tensor]:
     """gt_cache of evaluate_INN_forward (CWFA.py:146-195): level n+1 = low half of Haar1D(level n)."""

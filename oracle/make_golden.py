@@ -26,6 +26,11 @@ Fixture index:
   g13_step_grad_*       autograd gradients of the training NLL of one CAT step (CWFA.py:966-978,1002-1006)
   g14_unet_grad_*       autograd gradients of the UNet in train mode (unet.py:72-113,161-195)
   g15_meanbranch_grad   autograd gradients of the LRNN's mean-volume branch (networks.py:468-503,244-262,552-554)
+  g16_concat            Concat fwd / rev, three inputs              (graph_topology.py:92-152)
+  g17_fixed1x1conv      Fixed1x1Conv fwd / rev + log-det            (fixed_transforms.py:95-133)
+  g18_ai1_opt_*         AllInOneBlock options: soft permutation, learned householder, reverse permutation, SIGMOID / EXP
+                        global affine                               (all_in_one_block.py:122-196)
+  g19_meanvol / g19_denorm  mean-volume cache detail bands and the output de-normalisation (CWFA.py:637-655,1035-1044)
 """
 import os
 import sys
@@ -37,7 +42,8 @@ import numpy as np
 
 warnings.filterwarnings("ignore")
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+# CWFA_GOLDEN_OUT: write somewhere else (tests/test_make_golden.py regenerates into a temp dir and compares)
+OUT = os.environ.get("CWFA_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
 def import_reference():
@@ -60,6 +66,16 @@ def import_reference():
     import unet
     import CWFA
     return Ff, Fm, INN_utils, networks, unet, CWFA
+
+
+def fresh_process_state(networks):
+    """What a generator relies on must not depend on which generators ran before it in the same process: autograd on
+    (main() switches it off for the forward-only fixtures) and the ONE PReLU instance every ResidualBlock of the process
+    shares (a default argument, networks.py:209; G8 sets it to 0.2) back at its initial slope."""
+    import torch
+    torch.set_grad_enabled(True)
+    with torch.no_grad():
+        networks.ResidualBlock.__init__.__defaults__[-1].weight.fill_(0.25)
 
 
 def npy(t):
@@ -347,6 +363,30 @@ def main():
          seed_init=np.int64(41), seed_input=np.int64(4343), seed_ln=np.int64(4444))
 
 
+def gen_topology():
+    """G16 Concat, G17 Fixed1x1Conv (FrEIA API surface; VERDICT r1: no test anywhere)."""
+    import torch
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(1616)
+    dims = [(3, 5, 7), (2, 5, 7), (4, 5, 7)]
+    xs = [torch.randn(2, *d, generator=g) for d in dims]
+    cat = Fm.Concat(dims, dim=0)
+    (y,), jf = cat(xs, rev=False)
+    z = torch.randn(2, 9, 5, 7, generator=g)
+    parts, jr = cat((z,), rev=True)
+    dump("g16_concat", x0=npy(xs[0]), x1=npy(xs[1]), x2=npy(xs[2]), y_fwd=npy(y), z=npy(z),
+         r0=npy(parts[0]), r1=npy(parts[1]), r2=npy(parts[2]), jac_fwd=np.float64(jf), jac_rev=np.float64(jr),
+         out_dims=np.array(cat.output_dims(dims)[0], np.int64))
+    M = torch.randn(6, 6, generator=g) + 2.0 * torch.eye(6)
+    m = Fm.Fixed1x1Conv([(6, 9, 11)], M=M)
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    (yf,), jf = m((x,), rev=False)
+    (xr,), jr = m((x,), rev=True)
+    dump("g17_fixed1x1conv", M=npy(M), x=npy(x), y_fwd=npy(yf), y_rev=npy(xr), jac_fwd=np.float64(float(jf)),
+         jac_rev=np.float64(float(jr)), **sd_arrays(m))
+
+
 def gen_extract_views():
     """g12: the reference's XLFMDatasetFull.extract_views on small frames, windows clipped at every border."""
     import_reference()
@@ -371,6 +411,7 @@ def gen_step_grad():
     conditions, from the reference's own graph + torch autograd -- what `full_loss.backward()` (CWFA.py:1002-1006)
     produces for the log-likelihood term.  Steps built as run_CWFA does (CWFA.py:498-510), small channel counts."""
     Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    fresh_process_state(networks)
     import torch
     torch.set_num_threads(8)
     g = torch.Generator().manual_seed(1313)
@@ -440,6 +481,31 @@ def gen_step_grad():
             grads.update({"condgrad/" + k: npy(p.grad) for k, p in cond_net.named_parameters() if p.grad is not None})
             grads.update({"flowgrad_cond/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None})
             grads.update(sd_arrays(cond_net, "condsd/"))
+            # ... and with the condition net in TRAIN mode, as the reference runs the optimised step (CWFA.py:768,859):
+            # Dropout3d(0.5) on the hidden Conv3d channels (networks.py:224).  The draw is pinned harness-side: the Dropout3d
+            # module is swapped for a fixed keep / scale table with the same semantics (whole channels per sample, 1/(1-p)).
+            if ix == 0 and n_ch == 8:
+                blk = cond_net.subnetworks[0]
+                K = blk.conv3d[0].out_channels
+                mask = (torch.rand(B, K, generator=g) >= 0.5).float() / 0.5
+
+                class FixedDrop(torch.nn.Module):
+                    def forward(self, t):
+                        return t * mask.view(B, K, 1, 1, 1)
+                real_drop = blk.conv3d[2]
+                assert isinstance(real_drop, torch.nn.Dropout3d) and real_drop.p == 0.5
+                blk.conv3d[2] = FixedDrop()
+                for p in list(inn.parameters()) + list(cond_net.parameters()):
+                    p.grad = None
+                om4 = cond_net(views)[-1]
+                c4 = [om4, c[1].detach()]
+                xhat4, _ = inn([z_in, low_in], c=c4, rev=True)
+                Z4, ld4 = inn(x, c=c4)
+                full4 = w_c * F.mse_loss(x, xhat4) + (1 - w_c) * (0.5 * torch.norm(Z4[0]) ** 2 - ld4.mean()) / xhat4.numel()
+                full4.backward()
+                blk.conv3d[2] = real_drop
+                grads.update({"drop/mask": npy(mask), "drop/omega": npy(om4), "drop/loss": np.float64(full4.item())})
+                grads.update({"dropgrad/" + k: npy(p.grad) for k, p in cond_net.named_parameters() if p.grad is not None})
         dump(f"g13_step_grad_k{ix}_ch{n_ch}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z=npy(Z[0]), low=npy(Z[1]), loss=np.float64(loss.item()),
              gc0=npy(c[0].grad), gc1=npy(c[1].grad), D=np.int64(D), H=np.int64(H), W=np.int64(W), ix=np.int64(ix), S=np.int64(S),
              n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))
@@ -450,6 +516,7 @@ def gen_unet_grad():
     max-pool, skip additions, transposed convolutions (unet.py:72-113,161-195) -- from the reference's own modules and
     torch autograd, for an arbitrary upstream gradient.  Dropout off (the reference's dropout draws from torch's RNG)."""
     Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    fresh_process_state(networks)
     import torch
     torch.set_num_threads(8)
     g = torch.Generator().manual_seed(1414)
@@ -478,6 +545,7 @@ def gen_meanbranch_grad():
     att = GlobalAttention(mean), out = x + m*2*(att - 0.5) (networks.py:468-503,244-262,552-554) -- from the reference's
     modules and torch autograd.  drop_path off (it draws from torch's RNG)."""
     Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    fresh_process_state(networks)
     import torch
     torch.set_num_threads(8)
     g = torch.Generator().manual_seed(1515)
@@ -512,8 +580,11 @@ if __name__ == "__main__":
         gen_extract_views()
     elif len(sys.argv) > 1 and sys.argv[1] == "step_grad":
         gen_step_grad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "topology":
+        gen_topology()
     else:
         main()
+        gen_topology()
         gen_extract_views()
         gen_step_grad()
         gen_unet_grad()

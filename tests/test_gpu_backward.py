@@ -341,6 +341,29 @@ def test_training_loss_backward_into_the_condition_net_golden(name):
     gotf = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
     for k in sorted(wantf):
         assert_close(gotf[k], wantf[k], TOL, "flow step " + k)
+    if "drop/mask" in fx:
+        # the optimised step's condition net in TRAIN mode (CWFA.py:768,859): Dropout3d(0.5) on the hidden Conv3d channels
+        # with the draw pinned by the fixture's keep / scale table
+        for p in list(cond_net.parameters()) + list(g.parameters()):
+            p.grad = None
+        omega, ctape = training.cond_forward_train(cond_net, cu("cond/views"), drop_mask=cu("drop/mask"))
+        assert_close(omega, fx["drop/omega"], TOL, "omega with dropout")
+        out = training.step_backward(g, cu("x"), [omega, cu("c1")], low=cu("full/low_in"), z=cu("full/z_in"),
+                                     cond_weight=float(fx["full/w_c"]), loss_func="L2", want_cond_grads=True)
+        assert abs(float(out["full_loss"]) - float(fx["drop/loss"])) <= 1e-5 * abs(float(fx["drop/loss"]))
+        training.cond_backward(ctape, out["cond_grads"][0])
+        want = {k[len("dropgrad/"):]: v for k, v in fx.items() if k.startswith("dropgrad/")}
+        got = {k: p.grad for k, p in cond_net.named_parameters() if p.grad is not None}
+        assert set(got) == set(want), sorted(set(got) ^ set(want))
+        for k in sorted(want):
+            assert_close(got[k], want[k], TOL, "condition net (dropout) " + k)
+        # train mode without an explicit table draws one from torch's RNG: kept channels are scaled by 2, dropped ones vanish
+        cond_net.train()
+        try:
+            _, t2 = training.cond_forward_train(cond_net, cu("cond/views"))
+            assert t2.drop_mask is not None and set(t2.drop_mask.unique().tolist()) <= {0.0, 2.0}
+        finally:
+            cond_net.eval()
 
 
 def test_full_size_directional_derivative():

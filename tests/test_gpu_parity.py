@@ -335,6 +335,42 @@ def test_actnorm_golden():
     assert an2.init_on_next_batch is False
 
 
+def test_concat_golden():
+    """Concat (graph_topology.py:92-152): forward through the strided plane-copy kernel, reverse hands out views."""
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden("g16_concat")
+    dims = [tuple(fx[f"x{i}"].shape[1:]) for i in range(3)]
+    cat = Fm.Concat(dims, dim=0)
+    assert tuple(cat.output_dims(dims)[0]) == tuple(int(v) for v in fx["out_dims"])
+    (y,), j = cat([cu(fx["x0"]), cu(fx["x1"]), cu(fx["x2"])], rev=False)
+    assert torch.equal(y.cpu(), T(fx["y_fwd"])) and j == float(fx["jac_fwd"])
+    parts, jr = cat((cu(fx["z"]),), rev=True)
+    assert len(parts) == 3 and all(torch.equal(p_.cpu(), T(fx[f"r{i}"])) for i, p_ in enumerate(parts)) and jr == float(fx["jac_rev"])
+    # channel-sliced (strided) inputs and the deprecated aliases
+    big = cu(fx["z"])
+    (y2,), _ = cat([big[:, :3], big[:, 3:5], big[:, 5:]], rev=False)
+    assert torch.equal(y2, big)
+    with pytest.warns(DeprecationWarning):
+        Fm.ConcatChannel(dims)
+
+
+def test_fixed1x1conv_golden():
+    """Fixed1x1Conv (fixed_transforms.py:95-133): dense 1x1 on the MFMA conv kernel, both directions, log-det."""
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden("g17_fixed1x1conv")
+    m = Fm.Fixed1x1Conv([tuple(fx["x"].shape[1:])], M=T(fx["M"])).cuda()
+    for k, v in sd_of(fx).items():
+        assert_close(m.state_dict()[k], v, 1e-6, k)
+    (yf,), jf = m((cu(fx["x"]),), rev=False)
+    (yr,), jr = m((cu(fx["x"]),), rev=True)
+    assert_close(yf, fx["y_fwd"], 2e-6, "forward")
+    assert_close(yr, fx["y_rev"], 2e-5, "reverse")
+    assert abs(float(jf) - float(fx["jac_fwd"])) <= 1e-5 * abs(float(fx["jac_fwd"]))
+    assert abs(float(jr) - float(fx["jac_rev"])) <= 1e-5 * abs(float(fx["jac_rev"]))
+    (xb,), _ = m((yf,), rev=True)
+    assert_close(xb, fx["x"], 2e-5, "round trip")
+
+
 @pytest.mark.parametrize("name", names("g07_"))
 def test_subnets_golden(name):
     from cwfa_amd import networks as N

@@ -281,3 +281,19 @@ def test_mean_branch_gradients_vs_reference_autograd():
     for t in ("cn1", "cn2", "ga"):
         for k in [k[len(f"grad_{t}/"):] for k in fx if k.startswith(f"grad_{t}/")]:
             assert_close(sds[t][k].grad, fx[f"grad_{t}/" + k], 1e-4, f"{t}.{k}")
+
+
+def test_concat_and_fixed1x1conv_golden():
+    """FrEIA API surface outside the default graphs: Concat (graph_topology.py:92-152), Fixed1x1Conv (fixed_transforms.py:95-133)."""
+    fx = load_golden("g16_concat")
+    y, j = O.concat([T(fx["x0"]), T(fx["x1"]), T(fx["x2"])])
+    assert torch.equal(y, T(fx["y_fwd"])) and j == float(fx["jac_fwd"])
+    parts, jr = O.concat(None, rev_input=T(fx["z"]), sizes=[3, 2, 4])
+    assert all(torch.equal(p_, T(fx[f"r{i}"])) for i, p_ in enumerate(parts)) and jr == float(fx["jac_rev"])
+    fx = load_golden("g17_fixed1x1conv")
+    y, j = O.fixed1x1conv(T(fx["M"]), T(fx["x"]), False)
+    assert_close(y, fx["y_fwd"], 2e-6)
+    assert abs(j - float(fx["jac_fwd"])) <= 1e-5 * abs(float(fx["jac_fwd"]))
+    y, j = O.fixed1x1conv(T(fx["M"]), T(fx["x"]), True)
+    assert_close(y, fx["y_rev"], 2e-5)
+    assert abs(j - float(fx["jac_rev"])) <= 1e-5 * abs(float(fx["jac_rev"]))

@@ -13,9 +13,6 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 VARIANTS = {     # name -> (source the -D flags apply to, flags)
     "base": ("conv2d.hip", []),
-    "nodma": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NODMA"]),
-    "nobar": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NOBAR"]),
-    "nodma_nobar": ("conv2d.hip", ["-DCWFA_EXP_SPLIT_NODMA", "-DCWFA_EXP_SPLIT_NOBAR"]),
 }
 SHAPES = [  # (Cin, Cout, H, W, ks)
     (512, 512, 256, 256, 3), (1024, 1024, 128, 128, 3),
