@@ -453,7 +453,7 @@ def dwt_roofline(ops, step, a, dev, reps=20):
     big = [r for r in rows if r[2] == max(r2[2] for r2 in rows)]
     gbs = nbytes / (ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-           "kernel": "chain_inv_rows_kernel (in-path: inverse Haar1D + Split/cat + 5 x (gather, affine), one launch per flow step)",
+           "kernel": "chain_rows4_kernel<true> (in-path: inverse Haar1D + Split/cat + 5 x (gather, affine), one launch per flow step)",
            "bytes_per_volume": nbytes / 3 / a.batch, "us_per_volume": 1e3 * ms / 3 / a.batch, "launches_timed": len(rows),
            "largest_level": {"bytes_per_launch": 4.0 * 13 * big[0][1] * big[0][2] * big[0][3] * big[0][4],
                              "avg_launch_us": 1e3 * sum(r[5] for r in big) / len(big),

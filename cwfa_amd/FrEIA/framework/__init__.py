@@ -315,6 +315,17 @@ class _CatStepPlan:
     def __init__(self, graph, chain, flow_out_idx, low_out_idx):
         self.graph, self.chain = graph, chain
         self.flow_out_idx, self.low_out_idx = flow_out_idx, low_out_idx
+        self._tables = {}
+
+    def _composed(self, rev, perms, final_perm, shape, device):
+        """Per-axis composition of the direction's gathers (ops.chain_tables), cached while the permutation parameters
+        are unchanged."""
+        tabs = [t for t, _ in perms if t is not None] + ([final_perm] if final_perm is not None else [])
+        key = (tuple(shape), str(device), tuple((t.data_ptr(), t._version) for t in tabs))
+        hit = self._tables.get(rev)
+        if hit is None or hit[0] != key:
+            hit = self._tables[rev] = (key, ops.chain_tables(perms, final_perm, *shape, device))
+        return hit[1]
 
     def _stages(self, cond_of, rev, coefficients=None):
         """Stage list in execution order; every stage = (input gather, affine).  ``coefficients(module, conditions)``
@@ -337,6 +348,15 @@ class _CatStepPlan:
                 pending = None
         return stages, pending
 
+    @staticmethod
+    def _perms_of(stages):
+        """(table, axis) of every stage: the int64 tensor a stage keeps alive for its gather, or None."""
+        out = []
+        for st, keep in stages:
+            table = next((t for t in keep if t.dtype == torch.int64), None) if st.perm else None
+            out.append((table, int(st.perm_axis)))
+        return out
+
     def run(self, x_or_z, c, rev, sumsq=None, jac=True):
         """``jac=False`` skips the log-det reduction (the reconstruction loop discards it, CWFA.py:912) and returns
         ``None`` in its place."""
@@ -349,7 +369,8 @@ class _CatStepPlan:
             z, low = x_or_z[self.flow_out_idx], x_or_z[self.low_out_idx]
             if pending is not None:
                 stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
-            out = ops.chain_inv(z, low, stages, logdet=acc)
+            tabs = self._composed(True, self._perms_of(stages), None, tuple(low.shape[1:]), low.device)
+            out = ops.chain_inv(z, low, stages, logdet=acc, tables=tabs)
             res = out if not g.force_tuple_output else (out,)
             return res, (acc.to(torch.float32) if jac else None)
         final_perm = None
@@ -358,7 +379,9 @@ class _CatStepPlan:
                 final_perm = pending[0]
             else:
                 stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
-        z, low = ops.chain_fwd(first, stages, final_perm, logdet=acc, sumsq=sumsq)
+        shp = (first.shape[1] // 2, first.shape[2], first.shape[3])
+        tabs = self._composed(False, self._perms_of(stages), final_perm, shp, first.device)
+        z, low = ops.chain_fwd(first, stages, final_perm, logdet=acc, sumsq=sumsq, tables=tabs)
         outs = [None, None]
         outs[self.flow_out_idx], outs[self.low_out_idx] = z, low
         return tuple(outs), (acc.to(torch.float32) if jac else None)

@@ -24,7 +24,7 @@ class AffineStage(C.Structure):
 
 
 class Chain(C.Structure):
-    _fields_ = [("n_stages", C.c_int), ("stage", AffineStage * CHAIN_MAX)]
+    _fields_ = [("n_stages", C.c_int), ("stage", AffineStage * CHAIN_MAX), ("src_c", C.c_void_p), ("src_h", C.c_void_p)]
 
 
 class ChainGrads(C.Structure):

@@ -619,6 +619,135 @@ __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(const float* __rest
     }
 }
 
+// ---- the same with 16-byte accesses and every global load of a block in flight at once (the form that normally runs at
+// CWFA's sizes: W a multiple of 4 with W/4 dividing 256, 16-byte aligned rows).  A thread owns FOUR consecutive columns of
+// one row; a block of 256 threads owns 1024/W rows of one channel.  All row loads of all stages (s, t: 2n float4 per
+// thread, plus z / low or the x pair) are issued BEFORE the first use, so a block has its whole 13 - 14 row working set in
+// flight instead of one stage at a time (the row-at-a-time form above ran at 0.27 of the HBM peak: latency-bound).  The
+// coefficients are always read at the thread's own columns: a column permutation moves the travelling VALUES between the
+// threads of a row through an 8 KB LDS exchange (one barrier each), so occupancy is not limited by LDS and a chain without
+// column permutations uses none.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// s (clamped) and t of four columns from the raw float4 rows of a stage
+__device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4& sr, const f4& tr, f4& s, f4& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] = st.s_raw ? soft_clamp(sr[j] * st.pre_scale, st.clamp_kind, st.clamp) : 0.f;
+        t[j] = st.t ? (st.t_neg_div_sqrt2 ? (-tr[j]) / CWFA_SQRT2_F : tr[j] * st.pre_scale) : 0.f;
+    }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256) void chain_rows4_kernel(const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
+                                                          cwfa_chain ch, const int64_t* __restrict__ final_perm, int C, int H, int W,
+                                                          int64_t bs0, int64_t bs1, int64_t bs2, double* __restrict__ logdet,
+                                                          double* __restrict__ sumsq) {
+    // INV:  a0 = low [C], a1 = x out [2C], a2 = z in (may be null = zeros, const in effect)      (bs0, bs1, bs2 alike)
+    // !INV: a0 = x in [2C], a1 = low out [C], a2 = z out [C]
+    extern __shared__ float rows[];          // [2][row of the block][W]: exchange buffers of the travelling values (column gathers)
+    __shared__ double red[16];
+    const int tpr = W >> 2, RB = 256 / tpr;
+    const int r = threadIdx.x / tpr, w4 = (threadIdx.x - r * tpr) * 4;
+    const int b = blockIdx.z, c = blockIdx.y, hh = blockIdx.x * RB + r;
+    const bool live = hh < H;
+    const int h = live ? hh : H - 1;
+    const int64_t HW = (int64_t)H * W;
+    const int n = ch.n_stages;
+    RowPos q[CWFA_CHAIN_MAX], src = INV ? RowPos{c, h} : row_gather(RowPos{c, h}, final_perm, 1);
+    if (ch.src_c) {                          // composed by the caller: independent loads instead of a dependent walk
+#pragma unroll
+        for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+            if (k < n) q[k] = RowPos{ch.src_c[k * C + c], ch.src_h[k * H + h]};
+        src = RowPos{ch.src_c[n * C + c], ch.src_h[n * H + h]};
+    } else {
+#pragma unroll
+        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+            if (k < n) {
+                q[k] = src;
+                src = row_gather(src, ch.stage[k].perm, ch.stage[k].perm_axis);
+            }
+    }
+    // ---- every global load of this thread, back to back
+    f4 sr[CWFA_CHAIN_MAX], tr[CWFA_CHAIN_MAX];
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CWFA_CHAIN_MAX; ++k) {
+        sr[k] = tr[k] = zero;
+        if (k < n) {
+            const int64_t off = ((int64_t)q[k].c * H + q[k].h) * W + w4;
+            if (ch.stage[k].s_raw) sr[k] = *reinterpret_cast<const f4*>(ch.stage[k].s_raw + b * ch.stage[k].s_bs + off);
+            if (ch.stage[k].t) tr[k] = *reinterpret_cast<const f4*>(ch.stage[k].t + b * ch.stage[k].t_bs + off);
+        }
+    }
+    f4 v0 = zero, lo = zero, own0 = zero, own1 = zero;
+    const int64_t so = ((int64_t)src.h) * W + w4, oo = (int64_t)h * W + w4;
+    if constexpr (INV) {
+        if (a2) v0 = *reinterpret_cast<const f4*>(a2 + b * bs2 + (int64_t)src.c * HW + so);
+        lo = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)c * HW + oo);
+    } else {
+        const f4 e0 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * src.c) * HW + so);
+        const f4 e1 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * src.c + 1) * HW + so);
+        own0 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * c) * HW + oo);
+        own1 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * c + 1) * HW + oo);
+        v0 = (e0 - e1) * CWFA_INV_SQRT2_F;
+    }
+    // ---- coefficients at the thread's OWN four columns, then the chain.  A column permutation moves the travelling values
+    // between the threads of a row (through one LDS row, double-buffered: one barrier per column permutation); channel and
+    // row permutations only changed which rows were loaded above.
+    f4 ev[CWFA_CHAIN_MAX], tv[CWFA_CHAIN_MAX];
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+        if (k < n) {
+            f4 sv;
+            stage_st4(ch.stage[k], sr[k], tr[k], sv, tv[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ssum += sv[j];
+                ev[k][j] = __expf(INV ? -sv[j] : sv[j]);          // v_exp_f32(s * log2 e): |s| <= clamp, relative error ~2e-7
+            }
+        }
+    f4 v = v0;
+    int nx = 0;
+#pragma unroll
+    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+        if (k < n) {
+            if (ch.stage[k].perm && ch.stage[k].perm_axis == 3) {           // uniform over the block
+                float* buf = rows + (size_t)((nx & 1) * RB + r) * W;
+                ++nx;
+                *reinterpret_cast<f4*>(buf + w4) = v;
+                __syncthreads();
+                const int64_t* pk = ch.stage[k].perm + w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = buf[(int)pk[j]];
+            }
+            v = INV ? (v - tv[k]) * ev[k] : ev[k] * v + tv[k];
+        }
+    double sq = 0.0;
+    if (live) {
+        if constexpr (INV) {
+            *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)(2 * c) * HW + oo) = (lo + v) * CWFA_INV_SQRT2_F;
+            *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)(2 * c + 1) * HW + oo) = (lo - v) * CWFA_INV_SQRT2_F;
+        } else {
+            *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)c * HW + oo) = (own0 + own1) * CWFA_INV_SQRT2_F;
+            *reinterpret_cast<f4*>(a2 + b * bs2 + (int64_t)c * HW + oo) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sq += (double)v[j] * (double)v[j];
+        }
+    } else {
+        ssum = 0.f;
+    }
+    if (logdet) {
+        const double tot = cwfa_block_sum((double)ssum, red);
+        if (threadIdx.x == 0) atomicAdd(&logdet[b], INV ? -tot : tot);
+    }
+    if (!INV && sumsq) {
+        const double tot = cwfa_block_sum(sq, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq, tot);
+    }
+}
+
 // rows variant usable?  (LDS budget, grid limits)
 // Backward of  L = gscale * 0.5 * sum z^2  -  ldscale * sum_b logdet_b  (CWFA.py:970-978: gscale = 1/numel,
 // ldscale = 1/(B*numel)) through a whole forward chain in ONE launch and without stored activations: the flow is
@@ -754,6 +883,21 @@ static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size
     return *lds <= 60 * 1024 && C <= 65535 && B <= 65535 && W >= 64;
 }
 
+// 16-byte form usable?  W = 4 * (a divisor of 256), every row base and batch stride on a 16-byte boundary
+static bool chain_rows4_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds, const void* p0, const void* p1,
+                           const void* p2, int64_t bs0, int64_t bs1, int64_t bs2) {
+    if (W < 64 || (W & 3) || (W >> 2) > 256 || 256 % (W >> 2) != 0 || C > 65535 || B > 65535) return false;
+    if (!cwfa_aligned16(p0) || !cwfa_aligned16(p1) || (p2 && !cwfa_aligned16(p2)) || (bs0 & 3) || (bs1 & 3) || (p2 && (bs2 & 3))) return false;
+    for (int k = 0; k < ch->n_stages; ++k) {
+        const cwfa_affine_stage& st = ch->stage[k];
+        if ((st.s_raw && (!cwfa_aligned16(st.s_raw) || (st.s_bs & 3))) || (st.t && (!cwfa_aligned16(st.t) || (st.t_bs & 3)))) return false;
+    }
+    bool col = false;
+    for (int k = 0; k < ch->n_stages; ++k) col = col || (ch->stage[k].perm && ch->stage[k].perm_axis == 3);
+    *lds = col ? (size_t)2 * 1024 * sizeof(float) : 0;      // two exchange rows per block row, only for column gathers
+    return *lds <= 64 * 1024;
+}
+
 static int check_chain(const char* name, const cwfa_chain* ch) {
     CWFA_REQUIRE(ch, CWFA_E_INVAL, "%s: null chain", name);
     CWFA_REQUIRE(ch->n_stages >= 0 && ch->n_stages <= CWFA_CHAIN_MAX, CWFA_E_INVAL, "%s: %d stages (max %d)", name,
@@ -775,6 +919,13 @@ extern "C" int cwfa_chain_inv_f32(const float* z, const float* low, float* x, co
     const int64_t n = (int64_t)C * H * W;
     if (B == 0 || n == 0) return CWFA_OK;
     size_t lds;
+    if (chain_rows4_ok(ch, C, H, W, B, &lds, low, x, z, low_bs, x_bs, z_bs)) {
+        const int RB = 1024 / W;
+        hipLaunchKernelGGL(chain_rows4_kernel<true>, dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
+                           const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
+        CWFA_LAUNCH_CHECK("cwfa_chain_inv_f32");
+        return CWFA_OK;
+    }
     if (chain_rows_ok(ch, C, H, W, B, &lds)) {
         hipLaunchKernelGGL(chain_inv_rows_kernel, dim3(H, C, B), dim3(256), lds, (hipStream_t)stream, z, low, x, *ch, C, H, W,
                            z_bs, low_bs, x_bs, logdet);
@@ -798,6 +949,13 @@ extern "C" int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cw
     const int64_t n = (int64_t)C * H * W;
     if (B == 0 || n == 0) return CWFA_OK;
     size_t lds;
+    if (chain_rows4_ok(ch, C, H, W, B, &lds, x, low, z, x_bs, low_bs, z_bs)) {
+        const int RB = 1024 / W;
+        hipLaunchKernelGGL(chain_rows4_kernel<false>, dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
+                           *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
+        CWFA_LAUNCH_CHECK("cwfa_chain_fwd_f32");
+        return CWFA_OK;
+    }
     if (chain_rows_ok(ch, C, H, W, B, &lds)) {
         hipLaunchKernelGGL(chain_fwd_rows_kernel, dim3(H, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z, *ch, final_perm,
                            C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);

@@ -172,7 +172,7 @@ def channel_affine(x, scale, shift, inverse=False, perm_in=None, perm_out=None):
     return out
 
 
-def _chain(stages):
+def _chain(stages, tables=None):
     if len(stages) > _lib.CHAIN_MAX:
         raise ValueError(f"chain of {len(stages)} stages exceeds CWFA_CHAIN_MAX={_lib.CHAIN_MAX}")
     ch = Chain()
@@ -181,11 +181,36 @@ def _chain(stages):
     for k, (st, kp) in enumerate(stages):
         ch.stage[k] = st
         keep.append(kp)
+    if tables is not None:
+        ch.src_c, ch.src_h = (t.data_ptr() for t in tables)
+        keep.append(tables)
     return ch, keep
 
 
-def chain_inv(z, low, stages, logdet=None):
-    """x[B,2C,H,W] = Haar1D^-1(cat[low, A_{K-1}^-1(...A_0^-1(z))]); z may be None (= zeros)."""
+def chain_tables(perms, final_perm, C_, H, W, device):
+    """The gathers of a chain composed per axis (see cwfa_chain.src_* in include/cwfa_hip.h).  ``perms``: per stage in
+    execution order (table or None, axis).  Returns two int32 device tensors [n+1, C], [n+1, H]; built once per plan and
+    direction (a handful of tiny index ops) and reused by every launch.  (Column permutations are not composed: the
+    kernels move the values between threads instead.)"""
+    idx = {1: torch.arange(C_, device=device), 2: torch.arange(H, device=device)}
+    if final_perm is not None:
+        idx[1] = final_perm.to(device)[idx[1]]
+    n = len(perms)
+    rows = {1: [None] * (n + 1), 2: [None] * (n + 1)}
+    for k in range(n - 1, -1, -1):
+        for ax in (1, 2):
+            rows[ax][k] = idx[ax]
+        table, axis = perms[k]
+        if table is not None and axis in (1, 2):
+            idx[axis] = table.to(device)[idx[axis]]
+    for ax in (1, 2):
+        rows[ax][n] = idx[ax]
+    return tuple(torch.stack(rows[ax]).to(torch.int32).contiguous() for ax in (1, 2))
+
+
+def chain_inv(z, low, stages, logdet=None, tables=None):
+    """x[B,2C,H,W] = Haar1D^-1(cat[low, A_{K-1}^-1(...A_0^-1(z))]); z may be None (= zeros).  ``tables``: chain_tables()
+    of the stages' gathers (optional, speed only)."""
     L = _lib.lib()
     low, lbs = planes(low, "low")
     B, Cc, H, W = low.shape
@@ -194,7 +219,7 @@ def chain_inv(z, low, stages, logdet=None):
         z, zbs = planes(z, "z")
         if tuple(z.shape) != tuple(low.shape):
             raise ValueError(f"z {tuple(z.shape)} and low {tuple(low.shape)} differ")
-    ch, keep = _chain(stages)
+    ch, keep = _chain(stages, tables)
     out = torch.empty((B, 2 * Cc, H, W), dtype=torch.float32, device=low.device)
     rec = chain_event_sink
     if rec is not None:
@@ -208,13 +233,13 @@ def chain_inv(z, low, stages, logdet=None):
     return out
 
 
-def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None):
-    """(z, low) for x[B,2C,H,W]."""
+def chain_fwd(x, stages, final_perm=None, logdet=None, sumsq=None, tables=None):
+    """(z, low) for x[B,2C,H,W].  ``tables``: chain_tables() of the stages' gathers INCLUDING final_perm (optional)."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, D, H, W = x.shape
     Cc = D // 2
-    ch, keep = _chain(stages)
+    ch, keep = _chain(stages, tables)
     low = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
     z = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
     rec = chain_event_sink

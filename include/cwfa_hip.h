@@ -131,6 +131,14 @@ int cwfa_channel_affine_f32(const float* x, float* y, const float* scale, const 
 typedef struct {
     int n_stages;
     cwfa_affine_stage stage[CWFA_CHAIN_MAX];   /* in EXECUTION order for the requested direction */
+    /* Optional (both or none; device int32): the stages' channel / row gathers composed by the caller, so that a kernel
+     * reads where each stage takes its s,t rows from instead of walking the permutation tables (a chain of dependent
+     * loads): src_c [n_stages+1][C], src_h [n_stages+1][H]; row k < n_stages = the channel / image row at which stage k
+     * reads its coefficients for OUTPUT channel / row i, row n_stages = where the travelling value starts (for
+     * cwfa_chain_fwd_f32 the final permutation is part of the composition).  Used by the 16-byte row kernels of
+     * cwfa_chain_inv_f32 / cwfa_chain_fwd_f32; every other entry point ignores them. */
+    const int32_t* src_c;
+    const int32_t* src_h;
 } cwfa_chain;
 
 /* Inverse of one whole conditional step in ONE launch:  GraphINN.forward(rev=True) over
