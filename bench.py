@@ -151,6 +151,8 @@ def main():
                     "(warm-up + median of 3, all cores and 8 threads): several minutes")
     ap.add_argument("--no-lrnn", action="store_true", help="(diagnostic) flows + condition nets only")
     ap.add_argument("--no-experiment", action="store_true", help="skip the extra measurements after the timed region")
+    ap.add_argument("--split3x3-min", type=int, default=None, help="(tuning) smallest output-channel count of a 3x3 bank that takes "
+                    "the split-bf16 kernel in split / bf16 precision (library default: ops.SPLIT_3X3_MIN_COUT)")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -178,6 +180,8 @@ def main():
         global WINO2D_MIN
         WINO2D_MIN = a.wino2d
         ops.set_option("winograd_2d", a.wino2d)
+    if a.split3x3_min is not None:
+        ops.SPLIT_3X3_MIN_COUT = a.split3x3_min
     PREC = {"split": "split_bf16", "fp32": "fp32", "bf16": "bf16"}
     ops.set_precision(PREC[a.precision])
     products = {"split": SPLIT_PRODUCTS, "bf16": 1, "fp32": SPLIT_PRODUCTS}[a.precision]

@@ -92,7 +92,9 @@ SIGNATURES = {
     "cwfa_conv_split_packed_bytes": (i64, [i, i, i]),
     "cwfa_conv_split_pack_f32": (i, [p, p, i, i, i, i, p]),
     "cwfa_conv_split_f32": (i, [p, p, p, i, i, i, i, i, i, i64, C.POINTER(ConvOpts), p]),
-    "cwfa_conv3x3_split_fused_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_conv3x3_split_packed_bytes": (i64, [i, i]),
+    "cwfa_conv3x3_split_pack_f32": (i, [p, p, i, i, p]),
+    "cwfa_conv3x3_split_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),
     "cwfa_subnet_layer_split_pack_f32": (i, [p, p, p, p]),
     "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, p]),

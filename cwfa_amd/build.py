@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcwfa_hip.so")
-SOURCES = ["elementwise.hip", "conv2d.hip", "conv_wino.hip", "conv_wino2d.hip", "conv_split_layer.hip", "conv3d.hip", "lrnn_ops.hip", "conv_bwd.hip"]
+SOURCES = ["elementwise.hip", "conv2d.hip", "conv_wino.hip", "conv_wino2d.hip", "conv_split_layer.hip", "conv_split3x3.hip", "conv3d.hip", "lrnn_ops.hip", "conv_bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]

@@ -902,267 +902,21 @@ __global__ __launch_bounds__(512, 1) void conv1x1_split_kernel(SplitParams sp) {
     epilogue<C, EPI>(p, t, acc);
 }
 
-// 3x3: the same GEMM core with a nine-tap inner loop.  The haloed input tile of a 16-channel chunk
-// [piece][k half][10 rows][34 px] x 16 B stays in LDS for all nine taps (two buffers, DMA'd one chunk ahead; zero padding
-// and channels >= Cin come out of the buffer range check), a tap only shifts the B-operand address by a constant; the
-// weights arrive one 24.6 KB slice per tap-step through a three-buffer ring, two steps ahead.
-constexpr int CS3_XE = 3 * 2 * 10 * 34, CS3_XB = 2048 * 16;      // entries used / bytes reserved per input buffer (4 DMA items per thread)
-
-// MODE 0: the input comes pre-split from cwfa_split_input_f32 (LDS-DMA).  MODE 1 / 2: the kernel reads the fp32 tensor
-// itself and splits on the way into LDS -- a thread owns one or two (k half, row, column) entries of the tile, loads
-// their 8 channels early in a chunk, and late in the chunk applies the load-side affine (scale / shift tables held in
-// LDS), adds the skip tensor (MODE 2), splits and writes three 16-byte entries: no workspace, no extra HBM pass.
-enum { SPLIT_PRE = 0, SPLIT_FUSED = 1, SPLIT_FUSED_ADD = 2 };
-constexpr int CS3_AFF = 2 * 2048 * 4;                            // bytes: scale / shift tables for up to 2048 input channels
-
-template <int EPI, int MODE>
-__global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SplitParams sp) {
-    typedef CS C;
-    const ConvParams& p = sp.c;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);                   // [2 x CS3_XB input][3 x CS_WB weights][affine tables]
-    const Tile t = make_tile<C>(p);
-    const bool six = p.products != 1;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int64_t HW = (int64_t)p.H * p.W;
-    constexpr unsigned OOB = 0x80000000u;
-
-    unsigned xoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 512;
-        const int c = e % 34, r = (e / 34) % 10, h = (e / 340) % 2, piece = e / 680;
-        const int gr = t.row0 + r - 1, gc = t.col0 + c - 1;
-        const bool ok = e < CS3_XE && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-        xoff[i] = ok ? (unsigned)((((int64_t)piece * sp.CG2 + h) * HW + (int64_t)gr * p.W + gc) * 16) : OOB;
-    }
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sp.ws) + (int64_t)t.b * sp.ws_bs),
-                                                      0, (int)sp.ws_bs, 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.wp) + (int64_t)t.ct * p.nchunks * 9 * CS_WB), 0, p.nchunks * 9 * CS_WB,
-        0x00020000);
-    const int xchunk = (int)(2 * HW * 16);
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto dma_w = [&](int step, int wbuf) {        // steps past the end: out of range, zeros, never read
-        char* base = lds + 2 * CS3_XB + wbuf * CS_WB + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + i * 8192), 16, (unsigned)(tid + i * 512) * 16u, step * CS_WB, 0, 0);
-    };
-    auto dma_x = [&](int i, int chunk, int xbuf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(lds + xbuf * CS3_XB + wave * 1024 + i * 8192), 16, xoff[i],
-                                                 chunk * xchunk, 0, 0);
-    };
-
-    // ---- fused mode: entries e = tid and tid + 512 (< 680) of the [k half][10 rows][34 px] tile
-    constexpr bool FUSED = MODE != SPLIT_PRE, ADD = MODE == SPLIT_FUSED_ADD;
-    constexpr int NE = FUSED ? 2 : 1, NA = ADD ? 2 : 1;
-    unsigned fo[NE];
-    bool fok[NE], fin[NE];
-    float xv[NE][8], av[NA][8];
-    float* aff = reinterpret_cast<float*>(lds + 2 * CS3_XB + 3 * CS_WB);     // [scale 2048][shift 2048]
-    const bool has_aff = FUSED && p.o.in_scale != nullptr;
-    if constexpr (FUSED) {
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = tid + k * 512;
-            const int c = e % 34, r = (e / 34) % 10, h = (e / 340) & 1;
-            const int gr = t.row0 + r - 1, gc = t.col0 + c - 1;
-            fin[k] = e < 680;
-            fok[k] = fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-            fo[k] = fok[k] ? (unsigned)(((int64_t)h * 8 * HW + (int64_t)gr * p.W + gc) * 4) : OOB;
-        }
-        if (has_aff) {
-            const float* sc = p.o.in_scale + (int64_t)t.b * p.o.in_affine_bs;
-            const float* sh = p.o.in_shift + (int64_t)t.b * p.o.in_affine_bs;
-            for (int c = tid; c < 2048; c += 512) {
-                aff[c] = c < p.Cin ? sc[c] : 0.f;
-                aff[2048 + c] = c < p.Cin ? sh[c] : 0.f;
-            }
-        }
-    }
-    const int fbytes = (int)((int64_t)p.Cin * HW * 4);
-    const auto rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, FUSED ? fbytes : 0, 0x00020000);
-    const auto rfa = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(ADD ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : p.x), 0, ADD ? fbytes : 0, 0x00020000);
-    const int plane = (int)(HW * 4);
-    auto ldf = [](decltype(rf) r, unsigned vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
-    auto load_entry = [&](auto kc, int chunk) {
-        constexpr int k = decltype(kc)::value;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xv[k][j] = ldf(rf, fo[k], (chunk * 16 + j) * plane);
-        if constexpr (ADD) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) av[k][j] = ldf(rfa, fo[k], (chunk * 16 + j) * plane);
-        }
-    };
-    auto store_entry = [&](auto kc, int chunk, int xbuf) {
-        constexpr int k = decltype(kc)::value;
-        const int e = tid + k * 512;
-        const int ch0 = chunk * 16 + ((e / 340) & 1) * 8;
-        unsigned short pc[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = xv[k][j];
-            if (has_aff) v = fok[k] ? v * aff[(ch0 + j) & 2047] + aff[2048 + ((ch0 + j) & 2047)] : 0.f;     // padding stays zero
-            if constexpr (ADD) v += av[k][j];
-            unsigned short o[3] = {0, 0, 0};
-            if (six) split3(v, o);
-            else o[0] = __builtin_bit_cast(unsigned short, (__bf16)v);      // plain bf16 operands: the residual pieces are never read
-            pc[0][j] = o[0]; pc[1][j] = o[1]; pc[2][j] = o[2];
-        }
-        if (fin[k]) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (q > 0 && !six) continue;
-                uint4 u;
-                u.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
-                u.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
-                u.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
-                u.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
-                *reinterpret_cast<uint4*>(lds + xbuf * CS3_XB + (q * 680 + e) * 16) = u;
-            }
-        }
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    const char* alane = lds + 2 * CS3_XB + ((t.kh * 256) + t.wm * 64 + t.l31) * 16;          // + wbuf*CS_WB + (piece*512 + m*32)*16
-    const char* blane = lds + ((t.kh * 10 + t.wn * 4) * 34 + t.l31) * 16;                     // + xbuf*CS3_XB + (piece*680 + (n+dy)*34 + dx)*16
-
-    if constexpr (FUSED) {
-        __syncthreads();                                  // affine tables
-        load_entry(sc_int<0>{}, 0);
-        load_entry(sc_int<1>{}, 0);
-        store_entry(sc_int<0>{}, 0, 0);
-        store_entry(sc_int<1>{}, 0, 0);
-        dma_w(0, 0);
-        dma_w(1, 1);
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_x(i, 0, 0);
-        dma_w(0, 0);
-        dma_w(1, 1);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    // Operand registers: two A sets (the set of step t+1 is read in the second half of step t, AFTER the mid-step barrier
-    // that makes weight slice t+1 visible), B ring of two (the first B fragment of step t+1 is read during the last
-    // n-tile of step t: the input tile is complete long before).  Without this both waves of a SIMD sat through one LDS
-    // round trip after every barrier.
-    bf16x8 A[2][2][3], Bq[2][3];
-    auto load_a = [&](auto setc, int wb) {
-        constexpr int set = decltype(setc)::value;
-        const char* ab = alane + wb * CS_WB;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) A[set][m][q] = *reinterpret_cast<const bf16x8*>(ab + (q * 512 + m * 32) * 16);
-    };
-    load_a(sc_int<0>{}, 0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) Bq[0][q] = *reinterpret_cast<const bf16x8*>(blane + (q * 680) * 16);
-    int wbuf = 0, step = 0;
-    auto chunk_body = [&](auto parc, int chunk) {
-        constexpr int par = decltype(parc)::value;
-        const char* xb = blane + (chunk & 1) * CS3_XB;
-        const char* xn = blane + ((chunk + 1) & 1) * CS3_XB;
-        static_for<9>([&](auto tc) {
-            constexpr int tap = decltype(tc)::value, dy = tap / 3, dx = tap % 3, set = (par + tap) & 1;
-            constexpr int ntap = (tap + 1) % 9, ndy = ntap / 3, ndx = ntap % 3;
-            int nb = wbuf + 2;
-            nb = nb >= 3 ? nb - 3 : nb;
-            dma_w(step + 2, nb);
-            if constexpr (!FUSED) {
-                if constexpr (tap < 4) dma_x(tap, chunk + 1, (chunk + 1) & 1);  // next chunk's input tile, one item per step
-            } else {
-                // next chunk's entries: loads in the first two steps (past the last chunk: out of range, zeros), split and
-                // LDS stores in steps 6 and 7 -- before the barrier of step 8 that precedes the first read of that buffer
-                if constexpr (tap == 0) load_entry(sc_int<0>{}, chunk + 1);
-                if constexpr (tap == 1) load_entry(sc_int<1>{}, chunk + 1);
-                if constexpr (tap == 6) store_entry(sc_int<0>{}, chunk + 1, (chunk + 1) & 1);
-                if constexpr (tap == 7) store_entry(sc_int<1>{}, chunk + 1, (chunk + 1) & 1);
-            }
-            int w1 = wbuf + 1;
-            w1 = w1 == 3 ? 0 : w1;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (n < 3) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        Bq[(n + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(xb + (q * 680 + (n + 1 + dy) * 34 + dx) * 16);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        Bq[0][q] = *reinterpret_cast<const bf16x8*>((tap == 8 ? xn : xb) + (q * 680 + ndy * 34 + ndx) * 16);
-                }
-                if (n == 2) {
-                    // weight slice step+1 (issued one step ago) has landed everywhere; this step's own DMAs may stay in flight
-                    // allowed in flight: this step's own loads (3 weight DMAs + its input items)
-                    if constexpr (!FUSED) {
-                        if constexpr (tap < 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    } else if constexpr (tap < 2 && ADD) {
-                        asm volatile("s_waitcnt vmcnt(19)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    } else if constexpr (tap < 2) {
-                        asm volatile("s_waitcnt vmcnt(11)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_s_barrier();
-                    load_a(sc_int<set ^ 1>{}, w1);
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    f32x16 c = acc[m][n];
-                    if (six) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][2], Bq[n & 1][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][1], Bq[n & 1][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][m][0], Bq[n & 1][0], c, 0, 0, 0);
-                    acc[m][n] = c;
-                }
-            }
-            wbuf = w1;
-            ++step;
-        });
-    };
-    int chunk = 0;
-    for (; chunk + 1 < p.nchunks; chunk += 2) {
-        chunk_body(sc_int<0>{}, chunk);
-        chunk_body(sc_int<1>{}, chunk + 1);
-    }
-    if (chunk < p.nchunks) chunk_body(sc_int<0>{}, chunk);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    epilogue<C, EPI>(p, t, acc);
-}
-
-template <int EPI, int KS, int MODE = SPLIT_PRE>
+template <int EPI>
 int launch_split(SplitParams sp, hipStream_t stream) {
     ConvParams& p = sp.c;
     p.tiles_x = (p.W + CS::TC - 1) / CS::TC;
     p.tiles_y = (p.H + CS::TR - 1) / CS::TR;
     const int ctiles = (p.Cout + CS::CT - 1) / CS::CT;
     CWFA_REQUIRE((int64_t)p.tiles_x * p.tiles_y < (1ll << 31) && ctiles <= 65535 && p.B <= 65535, CWFA_E_SHAPE,
-                 "cwfa_conv1x1_split_f32: grid too large");
-    constexpr int LDS = KS == 1 ? 3 * CS_BUFB : 2 * CS3_XB + 3 * CS_WB + (MODE != SPLIT_PRE ? CS3_AFF : 0);
-    auto kern = KS == 1 ? &conv1x1_split_kernel<EPI> : &conv3x3_split_kernel<EPI, MODE>;
+                 "cwfa_conv_split_f32: grid too large");
+    constexpr int LDS = 3 * CS_BUFB;
+    auto kern = &conv1x1_split_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
-            cwfa_set_error("cwfa_conv1x1_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
+            cwfa_set_error("cwfa_conv_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS, hipGetErrorString(e));
             return CWFA_E_HIP;
         }
         attr_set = true;
@@ -1197,14 +951,14 @@ extern "C" int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, in
 }
 
 extern "C" int64_t cwfa_conv_split_packed_bytes(int Cout, int Cin, int ks) {
-    if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return -1;
-    return (int64_t)((Cout + 255) / 256) * ((Cin + 15) / 16) * ks * ks * CS_WB;
+    if (Cout <= 0 || Cin <= 0 || ks != 1) return -1;           // 3x3: cwfa_conv3x3_split_packed_bytes (conv_split3x3.hip)
+    return (int64_t)((Cout + 255) / 256) * ((Cin + 15) / 16) * CS_WB;
 }
 
 extern "C" int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int ks, int transposed, void* stream) {
     CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv_split_pack_f32: null pointer");
-    CWFA_REQUIRE(Cout > 0 && Cin > 0 && (ks == 1 || ks == 3) && (!transposed || (ks == 1 && Cout % 4 == 0)), CWFA_E_SHAPE,
-                 "cwfa_conv_split_pack_f32: bad shape");
+    CWFA_REQUIRE(Cout > 0 && Cin > 0 && ks == 1 && (!transposed || Cout % 4 == 0), CWFA_E_SHAPE,
+                 "cwfa_conv_split_pack_f32: bad shape (1x1 / transposed 2x2 only; 3x3: cwfa_conv3x3_split_pack_f32)");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv_split_pack_f32: packed image must be 16-byte aligned");
     const int nchunks = (Cin + 15) / 16, taps = ks * ks;
     const int64_t total = (int64_t)((Cout + 255) / 256) * nchunks * taps * 512;
@@ -1217,7 +971,7 @@ extern "C" int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, 
 extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                    int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
     CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv_split_f32: null pointer");
-    CWFA_REQUIRE(ks == 1 || ks == 3, CWFA_E_SHAPE, "cwfa_conv_split_f32: kernel size %d not in {1,3}", ks);
+    CWFA_REQUIRE(ks == 1, CWFA_E_SHAPE, "cwfa_conv_split_f32: kernel size %d (1x1 only; 3x3: cwfa_conv3x3_split_f32)", ks);
     SplitParams sp{};
     int rc = fill_params(sp.c, "cwfa_conv_split_f32", reinterpret_cast<const float*>(ws), reinterpret_cast<const float*>(w_packed), y,
                          B, Cin, H, W, Cout, 0, y_bs, opts);
@@ -1233,46 +987,10 @@ extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* 
                  "cwfa_conv_split_f32: one sample's planes / one cout tile's weights must stay below 2 GiB");
     const int epi = classify_epilogue(p.o);
     hipStream_t st = (hipStream_t)stream;
-    if (ks == 1) {
-        switch (epi) {
-            case EPI_NONE: return launch_split<EPI_NONE, 1>(sp, st);
-            case EPI_UP: return launch_split<EPI_UP, 1>(sp, st);
-            default: return launch_split<EPI_GENERIC, 1>(sp, st);
-        }
-    }
     switch (epi) {
-        case EPI_NONE: return launch_split<EPI_NONE, 3>(sp, st);
-        case EPI_PRELU: return launch_split<EPI_PRELU, 3>(sp, st);
-        default: return launch_split<EPI_GENERIC, 3>(sp, st);
-    }
-}
-
-extern "C" int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
-                                            int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
-    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "cwfa_conv3x3_split_fused_f32: null pointer");
-    SplitParams sp{};
-    int rc = fill_params(sp.c, "cwfa_conv3x3_split_fused_f32", x, reinterpret_cast<const float*>(w_packed), y, B, Cin, H, W, Cout, x_bs,
-                         y_bs, opts);
-    if (rc) return rc < 0 ? rc : CWFA_OK;
-    ConvParams& p = sp.c;
-    CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_fused_f32: upshuffle2 is a 1x1 feature");
-    CWFA_REQUIRE(Cin <= 2032, CWFA_E_SHAPE, "cwfa_conv3x3_split_fused_f32: at most 2032 input channels (affine tables in LDS)");
-    p.nchunks = (Cin + 15) / 16;
-    CWFA_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(p.nchunks * 9 + 2) * CS_WB < (1ll << 31), CWFA_E_SHAPE,
-                 "cwfa_conv3x3_split_fused_f32: one sample's input / one cout tile's weights must stay below 2 GiB");
-    const int epi = classify_epilogue(p.o);
-    hipStream_t st = (hipStream_t)stream;
-    if (p.o.in_add) {
-        switch (epi) {
-            case EPI_NONE: return launch_split<EPI_NONE, 3, SPLIT_FUSED_ADD>(sp, st);
-            case EPI_PRELU: return launch_split<EPI_PRELU, 3, SPLIT_FUSED_ADD>(sp, st);
-            default: return launch_split<EPI_GENERIC, 3, SPLIT_FUSED_ADD>(sp, st);
-        }
-    }
-    switch (epi) {
-        case EPI_NONE: return launch_split<EPI_NONE, 3, SPLIT_FUSED>(sp, st);
-        case EPI_PRELU: return launch_split<EPI_PRELU, 3, SPLIT_FUSED>(sp, st);
-        default: return launch_split<EPI_GENERIC, 3, SPLIT_FUSED>(sp, st);
+        case EPI_NONE: return launch_split<EPI_NONE>(sp, st);
+        case EPI_UP: return launch_split<EPI_UP>(sp, st);
+        default: return launch_split<EPI_GENERIC>(sp, st);
     }
 }
 

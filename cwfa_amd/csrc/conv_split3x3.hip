@@ -1,0 +1,480 @@
+// 3x3 convolution (stride 1, zero padding 1) with fp32-equivalent arithmetic on the bf16 matrix cores -- the UNet layers of
+// the LRNN (unet.py:94-113: 256 / 512 / 1024 channels) and, with the narrow tilings, the output convolutions of the coupling
+// sub-networks (networks.py:633-638).
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces (24 significand bits) and the six partial products with
+// i + j <= 4 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-24 relative); `split_products` = 1:
+// plain bf16 operands (BASELINE.json configs[4]).  The input is the fp32 tensor itself: the load-side prologue of the UNet
+// (BatchNorm affine x dropout mask of the producer, + skip tensor) is applied and the value split on the way into LDS.
+//
+// Block = 512 threads = 8 waves, two per SIMD, tile = CT = 64*MPW output channels x 8 rows x 32 pixels.  Wave (wm, wn) owns
+// 16*MPW channels x 4 rows: MPW m-tiles x 8 n-tiles of 16x16 accumulators (MPW = 4: 128 registers); a B fragment (16 bytes
+// per lane from LDS) feeds 6*MPW MFMAs and an A fragment 48.  (One wave per SIMD with the whole 256-pixel tile -- 256
+// accumulator registers -- was tried first: every issue cost of the single stream, LDS-DMA above all (12 instructions of
+// ~60 cycles per step), is then exposed: 225 TF/s against 260 for the two-wave form's predecessor.)
+//   K = 32 per MFMA = TWO (16-channel chunk, tap) units of the 9 * ceil(Cin / 16) a 3x3 has; lane group g = lane >> 4
+//   reads k-half g & 1 of unit g >> 1.  The haloed input tile of a chunk, [piece 3][k half 2][9 rows][34 px] x 16 B, sits
+//   in one of TWO LDS buffers (even / odd chunks); a tap only shifts the B-operand address.  A 9-step period covers an even
+//   and an odd chunk: taps (0,1)(2,3)(4,5)(6,7) of the even one, its tap 8 with tap 0 of the odd one, then (1,2)...(7,8).
+//   The even buffer is free from step 5 and refilled there (loads in steps 2..4), the odd one in steps 0..2 (loads in steps
+//   6..8 of the period before): buffer loads, padding / border / channels >= Cin come back as 0.0 from the range check.
+//   Weights: one slice [piece][k group 4][CT][8] per step through a two-slot ring by LDS-DMA, issued at the start of the
+//   step before, verified at its end; one barrier per step.
+#include "conv_internal.h"
+
+#include <utility>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
+
+namespace {
+
+constexpr int TR = 8, TC = 32, XR = TR + 2, XC = TC + 2, NT = TR;          // NT: n-tiles per wave (4 rows x 2 halves)
+constexpr int EPK = XR * XC;                // 306 entries per k half
+constexpr int KHB = 5440;                   // bytes of one k-half plane: 306 x 16 = 4896 padded to a multiple of 256 (bank phase)
+constexpr int XPB = 2 * KHB;                // one piece plane
+constexpr int XB = 3 * XPB;                 // one input buffer (30 720)
+static_assert(EPK * 16 <= KHB && EPK > 256 && EPK <= 384, "staging entry map");
+
+template <int MPW>
+struct Geo {
+    static constexpr int CT = 64 * MPW;                 // output channels per block
+    static constexpr int WSL = 3 * 4 * CT * 16;         // bytes of one weight slice (K = 32)
+    static constexpr int LDS = 2 * XB + 2 * WSL;        // MPW = 4: 159 744
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+struct SParams {
+    const float* x;
+    const void* wp;
+    float* y;
+    int B, Cin, H, W, Cout, nchunks, nsteps, tiles_x;
+    int64_t x_bs, y_bs;
+    cwfa_conv_opts o;
+};
+
+template <int K>
+struct ic {
+    static constexpr int value = K;
+};
+template <class F, int... S>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, S...>) {
+    (f(ic<S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <bool SIX>
+__device__ __forceinline__ void split3(float v, __bf16& a1, __bf16& a2, __bf16& a3) {
+    a1 = (__bf16)v;
+    if constexpr (SIX) {
+        const float r1 = v - (float)a1;
+        a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;
+        a3 = (__bf16)r2;
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_of(float v, float alpha) {
+    if constexpr (ACT == CWFA_ACT_ELU) return cwfa_elu(v);
+    if constexpr (ACT == CWFA_ACT_PRELU) return v > 0.f ? v : alpha * v;
+    if constexpr (ACT == CWFA_ACT_GELU) return cwfa_gelu(v);
+    if constexpr (ACT == CWFA_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+#define MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// byte offset of the B fragments of tap t in buffer `buf`, relative to the lane base
+__host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XB + ((tap / 3) * XC + tap % 3) * 16; }
+
+enum { EPI_RUNTIME = -1 };
+
+// ADD: a second tensor is added on load (UNet skip); ACT1: compile-time activation of the common epilogues (bias -> ACT1),
+// EPI_RUNTIME = whatever cwfa_conv_opts says (bias -> act -> + residual -> act2)
+template <int MPW, bool SIX, bool ADD, int ACT1>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
+    constexpr int CT = 64 * MPW;                        // output channels per block
+    constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it stays in SGPRs
+    const int wm = wave & 3, wn = wave >> 2;                            // channel group / row half of this wave
+    const int HW = p.H * p.W;
+    const int plane = HW * 4;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NQ = SIX ? 3 : 1;
+    constexpr int OFF_W = 2 * XB;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int b = blockIdx.z, ct = blockIdx.y;
+    const int row0 = (blockIdx.x / p.tiles_x) * TR, col0 = (blockIdx.x % p.tiles_x) * TC;
+
+    // ---- staging entries (two per thread): k = 0: k half wave >> 2, entries 0..255; k = 1: entries 256..339 of k half
+    // (wave >> 1) & 1 for waves 0..3 (so that the k half, hence the channel, is uniform over a wave)
+    constexpr int NEK = 2;
+    int ekh[NEK], eidx[NEK];
+    bool fin[NEK];
+    unsigned fo[NEK];
+    ekh[0] = wave >> 2; eidx[0] = tid & 255; fin[0] = true;
+    ekh[1] = (wave >> 1) & 1; eidx[1] = 256 + (tid & 127); fin[1] = wave < 4 && eidx[1] < EPK;
+    bool fok[NEK];
+#pragma unroll
+    for (int k = 0; k < NEK; ++k) {
+        const int r = eidx[k] / XC, c = eidx[k] % XC;
+        const int gr = row0 + r - 1, gc = col0 + c - 1;
+        fok[k] = fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
+        fo[k] = fok[k] ? (unsigned)((gr * p.W + gc) * 4) : OOB;
+    }
+    const int xbytes = p.Cin * plane;                   // channels >= Cin: out of range, 0.0
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)b * p.x_bs), 0, xbytes, 0x00020000);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? p.o.in_add + (int64_t)b * p.o.in_add_bs : p.x), 0,
+                                                      ADD ? xbytes : 0, 0x00020000);
+    const bool has_aff = p.o.in_scale != nullptr;
+    // the load-side affine tables are read through the SCALAR cache (constant address space; they were written by an
+    // earlier kernel and the channel index is uniform over a wave): as vector loads each cost a full memory round trip
+    // in the middle of the step
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* sc = has_aff ? (cfloat*)(p.o.in_scale + (int64_t)b * p.o.in_affine_bs) : nullptr;
+    cfloat* sh = has_aff ? (cfloat*)(p.o.in_shift + (int64_t)b * p.o.in_affine_bs) : nullptr;
+
+    auto load_entry = [&](auto kc, float (&xv)[8], float (&av)[8], int chunk) {
+        constexpr int k = decltype(kc)::value;
+        const int ch0 = chunk * 16 + ekh[k] * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo[k], (ch0 + j) * plane, 0));
+        if constexpr (ADD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, fo[k], (ch0 + j) * plane, 0));
+        }
+    };
+    auto store_entry = [&](auto kc, const float (&xv)[8], const float (&av)[8], int chunk, int buf) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 1 && !fin[1]) return;
+        const int ch0 = chunk * 16 + ekh[k] * 8;          // wave-uniform: the affine tables are read through scalar loads
+        bf16x8 pc[3];
+        float scv[8], shv[8];
+        if (has_aff) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = ch0 + j < p.Cin ? ch0 + j : p.Cin - 1;
+                scv[j] = ch0 + j < p.Cin ? sc[ch] : 0.f;
+                shv[j] = ch0 + j < p.Cin ? sh[ch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = xv[j];
+            if (has_aff) v = fok[k] ? v * scv[j] + shv[j] : 0.f;       // padding stays zero
+            if constexpr (ADD) v += av[j];
+            __bf16 a1, a2 = (__bf16)0.f, a3 = (__bf16)0.f;
+            split3<SIX>(v, a1, a2, a3);
+            pc[0][j] = a1; pc[1][j] = a2; pc[2][j] = a3;
+        }
+        char* dst = lds + buf * XB + ekh[k] * KHB + eidx[k] * 16;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
+    };
+
+    // ---- weight slices by LDS-DMA: WSL / 1024 wave instructions per slice, a quarter per wave
+    constexpr int NPC = WSL / 1024;                   // 1 KB pieces per slice (12 / 24 / 48), dealt round-robin over the 8 waves
+    const int64_t wtile = (int64_t)ct * p.nsteps * WSL;
+    const char* wbase = reinterpret_cast<const char*>(p.wp) + wtile;
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(wbase)), 0, p.nsteps * WSL, 0x00020000);
+    auto dma_w = [&](int slice, int slot) {              // slices past the end: out of range, zeros, never read
+        sfor<(NPC + 7) / 8>([&](auto ic_) {
+            constexpr int i = decltype(ic_)::value;
+            const int piece = i * 8 + wave;
+            if (piece < NPC) {                           // wave-uniform
+                char* dst = lds + OFF_W + slot * WSL + piece * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, (unsigned)(lane * 16), slice * WSL + piece * 1024, 0, 0);
+            }
+        });
+    };
+
+    const int alane = OFF_W + (g * CT + wm * MPW * 16 + c16) * 16;        // + slot*WSL + (q*4*CT + mt*16)*16
+    const int blane = (g & 1) * KHB + (wn * 4 * XC + c16) * 16;              // + tap_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
+    const bool sel = (g >> 1) != 0;
+
+    f32x4 acc[MPW][NT];
+#pragma unroll
+    for (int mt = 0; mt < MPW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int MH = MPW < 2 ? MPW : 2;            // m-tiles whose A fragments are held at a time (register budget)
+    bf16x8 A[MH][3], Bq[2][3];
+    float xa[NEK][8], xb[NEK][8], aa[NEK][8], ab[NEK][8];    // staged entries of the next even / odd chunk (+ skip tensor)
+
+    auto read_a = [&](int abase, int m0) {
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) A[mt][q] = *reinterpret_cast<const bf16x8*>(lds + abase + (q * 4 * CT + (m0 + mt) * 16) * 16);
+    };
+    auto read_b = [&](int set, int bbase, int nt) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            Bq[set][q] = *reinterpret_cast<const bf16x8*>(lds + bbase + q * XPB + ((nt >> 1) * XC + 16 * (nt & 1)) * 16);
+    };
+    auto mfma6 = [&](f32x4& c, const bf16x8 (&a)[3], const bf16x8 (&bb)[3]) {
+        if constexpr (SIX) {
+            MFMA(a[2], bb[0], c);
+            MFMA(a[1], bb[1], c);
+            MFMA(a[0], bb[2], c);
+            MFMA(a[1], bb[0], c);
+            MFMA(a[0], bb[1], c);
+        }
+        MFMA(a[0], bb[0], c);
+    };
+
+    // ---------------------------------------------------------------------------------------------- prologue
+    sfor<NEK>([&](auto kc) { load_entry(kc, xa[decltype(kc)::value], aa[decltype(kc)::value], 0); });
+    sfor<NEK>([&](auto kc) { load_entry(kc, xb[decltype(kc)::value], ab[decltype(kc)::value], 1); });
+    dma_w(0, 0);
+    sfor<NEK>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], aa[decltype(kc)::value], 0, 0); });
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    read_b(0, blane + (sel ? tap_off(0, 1) : tap_off(0, 0)), 0);          // step 0: taps 0 | 1 of chunk 0
+    // ONE step as the body of a rolled loop (the accumulators are loop-carried values: unrolling the nine steps of a period
+    // makes the register allocator split their live ranges and keep copies); P = position in the 9-step period
+    int sl = 0, P = 0, ce = 0;                           // ring slot of this step's slice; period position; even chunk of the period
+    for (int step = 0; step < p.nsteps; ++step) {
+        const int co = ce + 1;                            // odd chunk (past the end: all zeros, costs only time)
+        // units of this step: even chunk taps (2P, 2P+1) for P < 4; (tap 8 | odd tap 0) at P = 4; odd taps (2P-9, 2P-8) after
+        const int uA = 2 * P, uB = 2 * P + 1;
+        const int bufA = uA >= 9, tA = uA - 9 * bufA, bufB = uB >= 9, tB = uB - 9 * bufB;
+        const int offA = bufA * XB + ((tA / 3) * XC + tA % 3) * 16, offB = bufB * XB + ((tB / 3) * XC + tB % 3) * 16;
+        // -- order matters: in this rolled loop the compiler cannot count the vector-memory operations between a staging load
+        // and its use, so it waits for ALL of them (vmcnt(0)) before the split below: that must come BEFORE this step issues
+        // its own DMA and loads, when everything older has long landed (after them it cost 2 - 9 thousand cycles per step).
+        // the vector-heavy part of staging: split + LDS stores of one entry of the chunk after next
+        if (P == 0) store_entry(ic<0>{}, xb[0], ab[0], co, 1);
+        if (P == 1) store_entry(ic<1>{}, xb[1], ab[1], co, 1);
+        if (P == 5) store_entry(ic<0>{}, xa[0], aa[0], ce + 2, 0);
+        if (P == 6) store_entry(ic<1>{}, xa[1], aa[1], ce + 2, 0);
+        FENCE();
+        // first A fragments (the step's first B fragments were requested before the barrier of the step before)
+        const int abase = alane + sl * WSL;
+        const int bbase = blane + (sel ? offB : offA);
+        read_a(abase, 0);
+        FENCE();
+#pragma unroll
+        for (int m0 = 0; m0 < MPW; m0 += MH) {
+            if (m0 > 0) {
+                read_a(abase, m0);
+                read_b(0, bbase, 0);
+                FENCE();
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + 1 < NT) read_b((nt + 1) & 1, bbase, nt + 1);
+                FENCE();
+#pragma unroll
+                for (int mt = 0; mt < MH; ++mt) {
+                    mfma6(acc[m0 + mt][nt], A[mt], Bq[nt & 1]);
+                    FENCE();                 // keep the six products of a tile back to back (accumulator forwarding)
+                }
+                // this step's staging loads and the next weight slice are issued from INSIDE the MFMA stream (after the first
+                // n-tiles): issued in a burst right behind the barrier, all eight waves stood in their issue cost (~100 cycles per
+                // DMA instruction) at once with the matrix pipe idle; here the SIMD partner's MFMAs run meanwhile.  Loads BEFORE
+                // the DMA: they overwrite loop-carried registers, so the compiler waits for every older vector-memory
+                // operation first -- which must not include a DMA issued a moment ago.
+                if (m0 == 0 && nt == 0) {
+                    if (P == 2) load_entry(ic<0>{}, xa[0], aa[0], ce + 2);
+                    if (P == 3) load_entry(ic<1>{}, xa[1], aa[1], ce + 2);
+                    if (P == 6) load_entry(ic<0>{}, xb[0], ab[0], co + 2);
+                    if (P == 7) load_entry(ic<1>{}, xb[1], ab[1], co + 2);
+                    FENCE();
+                }
+                if (m0 == 0 && nt == 1) {
+                    dma_w(step + 1, sl ^ 1);
+                    FENCE();
+                }
+            }
+        }
+        // first B fragments of the next step: the input tiles it reads were completed at least two barriers ago
+        {
+            const int nP = P == 8 ? 0 : P + 1;
+            const int nA = 2 * nP, nB = 2 * nP + 1;
+            const int nbufA = nA >= 9, ntA = nA - 9 * nbufA, nbufB = nB >= 9, ntB = nB - 9 * nbufB;
+            const int noffA = nbufA * XB + ((ntA / 3) * XC + ntA % 3) * 16, noffB = nbufB * XB + ((ntB / 3) * XC + ntB % 3) * 16;
+            read_b(0, blane + (sel ? noffB : noffA), 0);
+            FENCE();
+        }
+        // the next slice (the youngest vector-memory operation of the step) has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (LDS: everything but the three B-fragment reads just issued is done, the staging stores of this step included)
+        if constexpr (SIX) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        sl ^= 1;
+        if (++P == 9) {
+            P = 0;
+            ce += 2;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // DMAs / loads past the end
+
+    // ---------------------------------------------------------------------------------------------- epilogue
+    // accumulator register r of tile (mt, nt): channel ct*CT + (wm*MPW + mt)*16 + 4g + r, pixel (row0 + 4*wn + nt/2, col0 + 16*(nt&1) + c16).
+    // Buffer stores: the descriptor ends at channel Cout and a pixel outside the image carries an out-of-range offset.
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)b * p.y_bs, 0, p.Cout * plane, 0x00020000);
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.o.residual ? p.o.residual + (int64_t)b * p.o.res_bs : p.y), 0,
+                                                      p.o.residual ? p.Cout * plane : 0, 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.o.bias ? p.o.bias : p.y), 0, p.o.bias ? p.Cout * 4 : 0, 0x00020000);
+    const float alpha = p.o.prelu_alpha ? *p.o.prelu_alpha : 0.f;
+    const int cwave = ct * CT + wm * MPW * 16;      // uniform: rides in the scalar offset
+    const unsigned glane = (unsigned)(4 * g) * (unsigned)plane;                           // the lane group's channel offset
+#pragma unroll
+    for (int mt = 0; mt < MPW; ++mt) {
+        float bias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = row0 + wn * 4 + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const unsigned po = (row < p.H && col < p.W) ? (unsigned)((row * p.W + col) * 4) + glane : OOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int soff = (cwave + mt * 16 + r) * plane;
+                float v = acc[mt][nt][r] + bias[r];
+                if constexpr (ACT1 == EPI_RUNTIME) {
+                    v = cwfa_act(v, p.o.act, alpha);
+                    if (p.o.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, po, soff, 0));
+                    v = cwfa_act(v, p.o.act2, alpha);
+                } else {
+                    v = act_of<ACT1>(v, alpha);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, po, soff, 0);
+            }
+            FENCE();                 // keep the results from being staged in registers all at once
+        }
+    }
+}
+
+// packed image: [cout tile][step][piece 3][k group 4][CT][8] of bf16; group g of step s = unit u = 2s + (g >> 1) =
+// (chunk u / 9, tap u % 9), k half g & 1: element j = w[co][chunk*16 + (g&1)*8 + j][tap] (0 beyond Cout / Cin / the last unit)
+template <int CT>
+__global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin,
+                                                            int nchunks, int nsteps, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [ctile][step][g 4][co CT]
+    if (i >= total) return;
+    const int col = (int)(i % CT), g = (int)((i / CT) % 4), s = (int)((i / (4 * CT)) % nsteps), ctile = (int)(i / ((int64_t)4 * CT * nsteps));
+    const int u = 2 * s + (g >> 1), chunk = u / 9, tap = u % 9, co = ctile * CT + col;
+    unsigned short pc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = chunk * 16 + (g & 1) * 8 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin && chunk < nchunks) v = w[((int64_t)co * Cin + ci) * 9 + tap];
+        __bf16 a1, a2, a3;
+        split3<true>(v, a1, a2, a3);
+        pc[0][j] = __builtin_bit_cast(unsigned short, a1);
+        pc[1][j] = __builtin_bit_cast(unsigned short, a2);
+        pc[2][j] = __builtin_bit_cast(unsigned short, a3);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint4 v4;
+        v4.x = pc[q][0] | ((unsigned)pc[q][1] << 16);
+        v4.y = pc[q][2] | ((unsigned)pc[q][3] << 16);
+        v4.z = pc[q][4] | ((unsigned)pc[q][5] << 16);
+        v4.w = pc[q][6] | ((unsigned)pc[q][7] << 16);
+        out[(((int64_t)ctile * nsteps + s) * 3 + q) * 4 * CT + g * CT + col] = v4;
+    }
+}
+
+inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 64 ? 2 : 1; }
+inline int nsteps_of(int Cin) { return 9 * (((Cin + 15) / 16 + 1) / 2); }      // whole 9-step periods of two 16-channel chunks
+
+template <int MPW, bool SIX, bool ADD, int ACT1>
+int launch(const SParams& p, hipStream_t stream) {
+    typedef Geo<MPW> G;
+    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) {
+            cwfa_set_error("cwfa_conv3x3_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", G::LDS, hipGetErrorString(e));
+            return CWFA_E_HIP;
+        }
+        attr_set = true;
+    }
+    const int tiles_y = (p.H + TR - 1) / TR, ctiles = (p.Cout + G::CT - 1) / G::CT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * tiles_y), ctiles, p.B), dim3(512), G::LDS, stream, p);
+    CWFA_LAUNCH_CHECK("cwfa_conv3x3_split_f32");
+    return CWFA_OK;
+}
+
+template <int MPW, bool SIX>
+int launch_epi(const SParams& p, hipStream_t st) {
+    const bool plain = !p.o.residual && p.o.act2 == CWFA_ACT_NONE;
+    if (p.o.in_add) {
+        if (plain && p.o.act == CWFA_ACT_PRELU) return launch<MPW, SIX, true, CWFA_ACT_PRELU>(p, st);
+        return launch<MPW, SIX, true, EPI_RUNTIME>(p, st);
+    }
+    if (plain && p.o.act == CWFA_ACT_PRELU) return launch<MPW, SIX, false, CWFA_ACT_PRELU>(p, st);
+    if (plain && p.o.act == CWFA_ACT_NONE) return launch<MPW, SIX, false, CWFA_ACT_NONE>(p, st);
+    return launch<MPW, SIX, false, EPI_RUNTIME>(p, st);
+}
+
+}  // namespace
+
+extern "C" int64_t cwfa_conv3x3_split_packed_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return -1;
+    const int ct = 64 * mpw_of(Cout);
+    return (int64_t)((Cout + ct - 1) / ct) * nsteps_of(Cin) * 3 * 4 * ct * 16;
+}
+
+extern "C" int cwfa_conv3x3_split_pack_f32(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv3x3_split_pack_f32: null pointer");
+    CWFA_REQUIRE(Cout > 0 && Cin > 0, CWFA_E_SHAPE, "cwfa_conv3x3_split_pack_f32: bad shape");
+    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv3x3_split_pack_f32: packed image must be 16-byte aligned");
+    const int mpw = mpw_of(Cout), ct = 64 * mpw, nchunks = (Cin + 15) / 16, nsteps = nsteps_of(Cin);
+    const int64_t total = (int64_t)((Cout + ct - 1) / ct) * nsteps * 4 * ct;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    uint4* out = reinterpret_cast<uint4*>(packed);
+    if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
+    else if (mpw == 2) hipLaunchKernelGGL(split3x3_pack_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
+    else hipLaunchKernelGGL(split3x3_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
+    CWFA_LAUNCH_CHECK("cwfa_conv3x3_split_pack_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                                      int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_conv3x3_split_f32: bad size");
+    if (B == 0 || H == 0 || W == 0) return CWFA_OK;
+    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "cwfa_conv3x3_split_f32: null pointer");
+    CWFA_REQUIRE(cwfa_aligned16(w_packed), CWFA_E_ALIGN, "cwfa_conv3x3_split_f32: packed weights must be 16-byte aligned");
+    SParams p{};
+    p.x = x; p.wp = w_packed; p.y = y;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
+    if (opts) p.o = *opts;
+    CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: upshuffle2 is a 1x1 feature");
+    CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "cwfa_conv3x3_split_f32: in_scale without in_shift");
+    CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
+                 "cwfa_conv3x3_split_f32: bad activation");
+    CWFA_REQUIRE(!((p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU) && !p.o.prelu_alpha), CWFA_E_INVAL,
+                 "cwfa_conv3x3_split_f32: PReLU without prelu_alpha");
+    p.nchunks = (Cin + 15) / 16;
+    p.nsteps = nsteps_of(Cin);
+    p.tiles_x = (W + TC - 1) / TC;
+    const int mpw = mpw_of(Cout);
+    CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(Cout + 64 * mpw) * H * W * 4 < (1ll << 31) &&
+                     (int64_t)(p.nsteps + 2) * 3 * 4 * 64 * mpw * 16 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv3x3_split_f32: one sample's input / output / one cout tile's weights must stay below 2 GiB");
+    CWFA_REQUIRE((int64_t)p.tiles_x * ((H + TR - 1) / TR) < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    const bool six = g_cwfa_split_products != 1;
+    if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
+    if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
+    return six ? launch_epi<1, true>(p, st) : launch_epi<1, false>(p, st);
+}

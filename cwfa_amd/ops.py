@@ -333,9 +333,13 @@ def pack_conv_weight(w, transposed=False):
         cout, cin, ks, kw = w.shape
         if ks != kw:
             raise ValueError("square kernels only")
-    if (_split_bf16 and ks == 1 and cout >= 128) or (_split_bf16 >= 2 and ks == 3 and cout >= 192):
+    if _split_bf16 and ks == 1 and cout >= 128:
         packed = torch.empty(L.cwfa_conv_split_packed_bytes(cout, cin, ks), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv_split_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv_split_pack")
+        return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
+    if _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT:
+        packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+        check(L.cwfa_conv3x3_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv3x3_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
     n = L.cwfa_conv2d_packed_floats(cout, cin, ks)
     if n <= 0:
@@ -402,10 +406,10 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-    if pc.split and pc.ks == 3 and _split_bf16 != 3:
+    if pc.split and pc.ks == 3:
         # fp32-accurate conv on the bf16 pipe, the kernel splits x on the way into LDS (prologue included)
-        check(L.cwfa_conv3x3_split_fused_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o),
-                                             _stream()), "conv3x3_split_fused")
+        check(L.cwfa_conv3x3_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o),
+                                       _stream()), "conv3x3_split")
     elif pc.split:
         # fp32-accurate GEMM on the bf16 pipe: one pass splits x (with the load-side prologue) into three bf16 planes
         ws = torch.empty(L.cwfa_split_workspace_bytes(B, Cin, H * W), dtype=torch.uint8, device=x.device)
@@ -424,6 +428,7 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
     return out
 
 
+SPLIT_3X3_MIN_COUT = 33     # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2
 conv_event_sink = None      # object with want(key)->bool and add(key, start_event, end_event); set by bench.py only
 
 
@@ -843,8 +848,7 @@ def set_option(name, value):
     run as an fp32-accurate GEMM on the bf16 matrix pipe (cwfa_split_input_f32 + cwfa_conv_split_f32)."""
     global _split_bf16, _pack_epoch
     _pack_epoch += 1
-    if name == "split_bf16":          # 0 off, 1: 1x1 / transposed convs, 2: also 3x3 convs with >= 192 output channels
-        #                                 (3: as 2 but the 3x3 kernel reads pre-split planes: the A/B reference for 2)
+    if name == "split_bf16":          # 0 off, 1: 1x1 / transposed convs, 2: also 3x3 convs and the fused 64-channel layers
         _split_bf16 = int(value)
         return
     check(_lib.lib().cwfa_set_option(name.encode(), int(value)), "set_option")

@@ -263,10 +263,14 @@ int cwfa_split_input_f32(const float* x, void* ws, int B, int Cin, int64_t HW, i
                          const float* in_shift, int64_t in_affine_bs, const float* in_add, int64_t in_add_bs, void* stream);
 int64_t cwfa_conv_split_packed_bytes(int Cout, int Cin, int ks);
 int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, int Cin, int ks, int transposed, void* stream);
-/* 3x3 only: the same computation straight from the fp32 tensor (the kernel splits on the way into LDS and applies the
- * load-side affine / added tensor of `opts` itself): no workspace, no extra pass. */
-int cwfa_conv3x3_split_fused_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
-                                 int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
+/* 3x3 (stride 1, zero padding 1) with the same arithmetic straight from the fp32 tensor: the kernel applies the load-side
+ * affine / added tensor of `opts` and splits on the way into LDS (no workspace, no extra pass); v_mfma_f32_16x16x32_bf16,
+ * one wave per SIMD (csrc/conv_split3x3.hip).  packed = cwfa_conv3x3_split_pack_f32(torch weight [Cout,Cin,3,3]):
+ * cwfa_conv3x3_split_packed_bytes(Cout, Cin) bytes, 16-byte aligned.  Epilogue: bias / act / residual / act2 of `opts`. */
+int64_t cwfa_conv3x3_split_packed_bytes(int Cout, int Cin);
+int cwfa_conv3x3_split_pack_f32(const float* w, void* packed, int Cout, int Cin, void* stream);
+int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                           int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 

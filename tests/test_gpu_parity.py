@@ -858,11 +858,13 @@ def test_split_bf16_conv_transpose():
     assert_close(y, torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2), 2e-6)
 
 
-@pytest.mark.parametrize("level", [2, 3])
-@pytest.mark.parametrize("cfg", [(1, 70, 7, 63, 200), (1, 256, 8, 64, 256), (2, 20, 12, 37, 320)])
-def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
-    """The nine-tap split-bf16 kernel (option value 2): zero padding through the buffer range check, the load-side
-    prologue applied by the split pass, specialised and generic epilogues."""
+@pytest.mark.parametrize("cfg", [(1, 70, 7, 63, 200), (1, 256, 8, 64, 256), (2, 20, 12, 37, 320), (1, 6, 19, 40, 256),
+                                 (1, 48, 9, 33, 130), (2, 33, 17, 50, 520), (1, 64, 16, 32, 96), (1, 64, 5, 20, 12)])
+def test_split_bf16_3x3_is_fp32_accurate(cfg):
+    """The split-bf16 3x3 kernel (K = 32 tap pairs on v_mfma_f32_16x16x32_bf16; tilings of 256 / 128 / 64 output channels):
+    zero padding and the channel tail through the buffer range check, odd and even chunk counts, the load-side prologue
+    applied by the kernel itself, specialised and run-time epilogues, per-sample affine tables."""
+    level = 2
     from cwfa_amd import ops
     B, Cin, H, W, Cout = cfg
     F = torch.nn.functional
@@ -877,7 +879,9 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
     lin_pro = F.conv2d(xin, w.double(), b.double(), padding=1)
-    ops.set_option("split_bf16", level)       # 2: the kernel splits on the fly, 3: pre-split planes
+    ops.set_option("split_bf16", level)
+    keep_min = ops.SPLIT_3X3_MIN_COUT
+    ops.SPLIT_3X3_MIN_COUT = 1                 # also the narrow tilings
     try:
         pc = ops.pack_conv_weight(w.cuda())
         assert pc.split
@@ -889,6 +893,7 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg, level):
                "aff_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
                                        in_shift=sh.cuda())}
     finally:
+        ops.SPLIT_3X3_MIN_COUT = keep_min
         ops.set_option("split_bf16", 0)
     lin_aff = F.conv2d(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), w.double(), b.double(), padding=1)
     want = {"plain": ref, "prelu": F.prelu(ref, alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
