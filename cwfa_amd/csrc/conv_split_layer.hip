@@ -244,21 +244,25 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         // ------------------------------------------------------------------------------------------ 18 conv steps
         sfor<18>([&](auto sc) {
             constexpr int S = decltype(sc)::value, P = S % 9, PER = S / 9;
-            // -- the slice DMA(s) first, then this step's staging loads (which may stay in flight across the barrier)
             const int s1 = next_slot(cs), s2 = next_slot(s1);
-            if constexpr (S == 0) dma_w(1, s1);                 // (late by one step: the 1x1 phase counts as one)
-            dma_w(S + 2, s2);
             constexpr bool LOADS = (P >= 2 && P <= 4) || P >= 6;
-            if constexpr (P >= 2 && P <= 4) {                   // even chunk 2*PER+2 (PER = 1: chunk 0 of the next tile)
-                constexpr int k = P - 2;
-                if constexpr (PER == 0) load_entry(xa[k], xs_cur, fo_c[k], 2);
-                else load_entry(xa[k], xs_next, fo_n[k], 0);
-            }
-            if constexpr (P >= 6) {                             // odd chunk 2*PER+3 (PER = 1: chunk 1 of the next tile)
-                constexpr int k = P - 6;
-                if constexpr (PER == 0) load_entry(xb[k], xs_cur, fo_c[k], 3);
-                else load_entry(xb[k], xs_next, fo_n[k], 1);
-            }
+            // the slice DMA(s), then this step's staging loads (which may stay in flight across the barrier) -- issued from
+            // INSIDE the MFMA stream, after the first m-tile: in a burst right behind the barrier all eight waves stood in
+            // their issue cost (~100 cycles per DMA instruction) at once with the matrix pipe idle
+            auto issue_memory = [&]() {
+                if constexpr (S == 0) dma_w(1, s1);             // (late by one step: the 1x1 phase counts as one)
+                dma_w(S + 2, s2);
+                if constexpr (P >= 2 && P <= 4) {               // even chunk 2*PER+2 (PER = 1: chunk 0 of the next tile)
+                    constexpr int k = P - 2;
+                    if constexpr (PER == 0) load_entry(xa[k], xs_cur, fo_c[k], 2);
+                    else load_entry(xa[k], xs_next, fo_n[k], 0);
+                }
+                if constexpr (P >= 6) {                         // odd chunk 2*PER+3 (PER = 1: chunk 1 of the next tile)
+                    constexpr int k = P - 6;
+                    if constexpr (PER == 0) load_entry(xb[k], xs_cur, fo_c[k], 3);
+                    else load_entry(xb[k], xs_next, fo_n[k], 1);
+                }
+            };
             const int ab = alane + cs * WSL;
             if constexpr (S == 1) read_a(0, ab, 0);             // slice 1 became visible with the barrier of step 0
             constexpr int NS = (S + 1) % 18;                    // next step's B base (step 17: unused, the 1x1 phase follows)
@@ -280,8 +284,11 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                         FENCE();
                     }
                 }
-                // the vector-heavy part of staging after the first m-tile: split + LDS stores of one entry
+                // after the first m-tile: this step's memory traffic, and the vector-heavy part of staging (split + LDS stores
+                // of one entry)
                 if (mt == 0) {
+                    issue_memory();
+                    FENCE();
                     if constexpr (P <= 2) store_entry(ic<P>{}, xb[P], 1);
                     if constexpr (P >= 5 && P <= 7) store_entry(ic<P - 5>{}, xa[P - 5], 0);
                     FENCE();

@@ -8,5 +8,5 @@ python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("/root/repo/gpurun_out/prof_$1/p_kernel_stats.csv")))
 for r in rows[:${2:-18}]:
-    print(r["Name"].replace("(anonymous namespace)::","")[:96], int(r["Calls"])//16, round(float(r["TotalDurationNs"])/16e6,3), r["Percentage"])
+    print(r["Name"].replace("(anonymous namespace)::","")[:96], int(r["Calls"])//13, round(float(r["TotalDurationNs"])/13e6,3), r["Percentage"])
 PY
