@@ -14,7 +14,8 @@ from . import ops
 
 __all__ = ["sample_z_truncated", "check_empty_depths", "evaluate_INN_forward", "inverse_pass", "nll_step",
            "nll_terms", "allreduce_nll", "build_networks", "step_log_likelihoods", "allgather_scores", "detect_ood",
-           "forward_nll_pass"]
+           "forward_nll_pass", "mean_volume_cache", "save_mean_volume_cache", "load_mean_volume_cache",
+           "denormalise_prediction", "denormalise_ground_truth"]
 
 
 def _no_grad_trunc_normal_(tensor, mean=0., std=1., a=-1., b=1.):
@@ -258,3 +259,69 @@ def build_networks(n_depths=96, side=512, max_down_steps=5, block_type="CAT", n_
         enc.train()                                     # CWFA.py:532: BatchNorm batch statistics, dropout, drop_path
         cond_nets.append(enc)
     return conv_inn, cond_nets
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mean-volume cache and output step
+# ---------------------------------------------------------------------------------------------------------------------
+def mean_volume_cache(gt_levels):
+    """The per-step second condition of the flows: for every level of the forward pyramid of a (normalised) mean volume
+    -- ``evaluate_INN_forward``'s gt_cache -- the difference of the even and odd depth planes of its FIRST sample,
+    ``gt[0, ::2] - gt[0, 1::2]`` (CWFA.py:655).  One channel gather (even planes | odd planes) and one subtraction per
+    level on the HIP kernels; returns tensors [D_n / 2, H, W] like the reference."""
+    out = []
+    for gt in gt_levels:
+        if gt is None:
+            continue
+        D = gt.shape[1]
+        order = torch.cat([torch.arange(0, D, 2), torch.arange(1, D, 2)]).to(gt.device)
+        eo = ops.gather(gt[:1], order, 1)                                  # [1, D, H, W]: even planes, then odd planes
+        out.append(ops.axpby(eo[:, :D // 2], 1.0, eo[:, D // 2:], -1.0)[0])
+    return out
+
+
+def save_mean_volume_cache(path, cache):
+    """``torch.save({'mean_vol_gt_cache': [...cpu tensors...]}, path)`` -- the file main.py:377 writes (named
+    ``mean_vol_{N}Imgs_ds_{id}_{split}`` there)."""
+    torch.save({'mean_vol_gt_cache': [v.detach().cpu() for v in cache]}, path)
+
+
+def load_mean_volume_cache(path_or_dir, device="cpu", dataset_id=None, split=None):
+    """Read a mean-volume cache as CWFA.py:637-640 does: ``path_or_dir`` is the file, or with ``dataset_id`` and ``split`` the
+    directory searched for ``mean_vol_*ds_{dataset_id}_{split}`` (first match).  The file holds plain tensors: it is read
+    with ``weights_only=True`` (nothing in it is executed).  Returns the list moved to ``device``, or None if no file matches."""
+    import glob
+    import os
+    path = path_or_dir
+    if dataset_id is not None:
+        hits = sorted(glob.glob(os.path.join(str(path_or_dir), f"mean_vol_*ds_{dataset_id}_{split}")))
+        if not hits:
+            return None
+        path = hits[0]
+    data = torch.load(path, map_location="cpu", weights_only=True)
+    return [v.to(device) for v in data['mean_vol_gt_cache']]
+
+
+def denormalise_prediction(stored_volume, std_vols, mean_vols):
+    """The evaluation branch's predicted output volume, CWFA.py:1041:
+    ``(stored_volumes[0][0] * 2**len(stored_volumes[0])) * std_vols + mean_vols`` -- first sample of the finest reconstruction;
+    the factor is 2 to the power of the BATCH length of that tensor, exactly as the reference has it.  One per-channel
+    affine launch (scale and shift are the same scalar for every depth; a power of two commutes with the rounding of the
+    product, and the kernel multiplies, then adds, like the reference)."""
+    x = stored_volume[:1]
+    C_ = x.shape[1]
+    scale = (torch.as_tensor(std_vols, dtype=torch.float32).reshape(()) * float(2 ** len(stored_volume))).to(x.device)
+    shift = torch.as_tensor(mean_vols, dtype=torch.float32).reshape(()).to(x.device)
+    return ops.channel_affine(x, scale.expand(C_).contiguous(), shift.expand(C_).contiguous())[0]
+
+
+def denormalise_ground_truth(gt_volume, std_vols, mean_vols):
+    """The ground-truth volume of the evaluation branch, CWFA.py:1037-1038: ``gt[0] * std + mean`` shifted so that its minimum
+    is 0.  The affine is the HIP kernel; the minimum and its subtraction are two torch reductions / elementwise ops on the
+    result (output bookkeeping after the path, like the metrics that follow it in the reference)."""
+    x = gt_volume[:1]
+    C_ = x.shape[1]
+    scale = torch.as_tensor(std_vols, dtype=torch.float32).reshape(()).to(x.device)
+    shift = torch.as_tensor(mean_vols, dtype=torch.float32).reshape(()).to(x.device)
+    v = ops.channel_affine(x, scale.expand(C_).contiguous(), shift.expand(C_).contiguous())[0]
+    return v - v.min()

@@ -94,8 +94,15 @@ class _TwoSided(_BaseCouplingBlock):
         return (out,), (as_jac(acc) if acc is not None else 0.)
 
     def _couple(self, xa, ya, parts, which, n_out, rev, acc):
+        net = self._fusable_net(which)
+        if net is not None and net.couple(parts, xa, ya, self.clamp_kind, self.clamp, 1.0, rev, acc):
+            return                      # s, t stayed in the accumulators of the sub-network's last convolution
         s_raw, t = self._nets(which, parts, n_out)
         ops.affine(xa, self._stage(s_raw, t, gin=self._gin), rev, logdet=acc, out=ya)
+
+    def _fusable_net(self, which):
+        """The sub-network that predicts [s | t] of coupling ``which`` if it can apply the coupling itself."""
+        return None
 
 
 class NICECouplingBlock(_TwoSided):
@@ -144,6 +151,10 @@ class GLOWCouplingBlock(_TwoSided):
         s_raw, t, _ = subnet_st(self.subnet1 if which == 1 else self.subnet2, parts, n_out)
         return s_raw, t
 
+    def _fusable_net(self, which):
+        net = self.subnet1 if which == 1 else self.subnet2
+        return net if (not self._gin and self.clamp_kind is not None and hasattr(net, "couple")) else None
+
 
 class GINCouplingBlock(GLOWCouplingBlock):
     """Volume preserving: the channel mean of s is removed at every pixel, log-det 0.  coupling_layers.py:305-381."""
@@ -162,10 +173,12 @@ class AffineCouplingOneSided(_BaseCouplingBlock):
         x0 = x[0]
         l1 = self.split_len1
         x1, x2 = x0[:, :l1], x0[:, l1:]
-        s_raw, t, _ = subnet_st(self.subnet, self._cond(x1, c), self.split_len2)
         out = ops.concat_channels([x1, x2])           # x1 passes through; x2 half is overwritten below
         acc = new_logdet(x0)
-        ops.affine(x2, self._stage(s_raw, t), rev, logdet=acc, out=out[:, l1:])
+        if not (self.clamp_kind is not None and hasattr(self.subnet, "couple") and
+                self.subnet.couple(self._cond(x1, c), x2, out[:, l1:], self.clamp_kind, self.clamp, 1.0, rev, acc)):
+            s_raw, t, _ = subnet_st(self.subnet, self._cond(x1, c), self.split_len2)
+            ops.affine(x2, self._stage(s_raw, t), rev, logdet=acc, out=out[:, l1:])
         return (out,), as_jac(acc)
 
 
@@ -199,10 +212,11 @@ class AllInOneBlock(InvertibleModule):
     """GLOW-style block: one-sided affine coupling (tanh clamp, coefficients x0.1) + per-channel global affine
     (softplus) + fixed channel permutation.  all_in_one_block.py:45-268.
 
-    Supported: hard permutation, SOFTPLUS / SIGMOID / EXP global affine, conditions.  Not on the HIP path (unused by
-    CWFA, which builds the block with defaults, networks.py:295,341-351): gin_block, permute_soft,
-    learned_householder_permutation, reverse_permutation -> NotImplementedError at construction.
-    """
+    Hard permutations (the default, what CWFA builds: networks.py:295,341-351) are index gathers fused with the global
+    affine (bit-exact).  The other options of the reference run too: ``permute_soft`` (a random SO(C) matrix) and
+    ``learned_householder_permutation`` are dense C x C mixes = 1x1 convolutions on the MFMA kernel;
+    ``reverse_permutation`` pre-multiplies with the inverse mix; ``gin_block`` removes the per-sample mean of s over
+    (C, H, W) (:218-219) and drops the global scale (:183-185)."""
 
     def __init__(self, dims_in, dims_c=[], subnet_constructor: Callable = None, affine_clamping: float = 2.,
                  gin_block: bool = False, global_affine_init: float = 1., global_affine_type: str = 'SOFTPLUS',
@@ -214,9 +228,6 @@ class AllInOneBlock(InvertibleModule):
         self.input_rank = len(dims_in[0]) - 1
         if self.input_rank != 2:
             raise ValueError("cwfa_amd AllInOneBlock handles image data [C,H,W] only")
-        if gin_block or permute_soft or learned_householder_permutation or reverse_permutation:
-            raise NotImplementedError("AllInOneBlock: gin_block / permute_soft / learned_householder_permutation / "
-                                      "reverse_permutation are outside the CWFA hot path and have no HIP kernel")
         if len(dims_c) == 0:
             self.conditional, self.condition_channels = False, 0
         else:
@@ -226,8 +237,14 @@ class AllInOneBlock(InvertibleModule):
         self.splits = [channels - channels // 2, channels // 2]
         self.in_channels = channels
         self.clamp = affine_clamping
-        self.GIN = False
+        self.GIN = bool(gin_block)
+        self.reverse_pre_permute = bool(reverse_permutation)
+        self.householder = int(learned_householder_permutation)
         self.global_affine_type = global_affine_type
+        if permute_soft and channels > 512:
+            import warnings
+            warnings.warn(("Soft permutation will take a very long time to initialize "
+                           f"with {channels} feature channels. Consider using hard permutation instead."))
         if global_affine_type == 'SIGMOID':
             global_scale = 2. - np.log(10. / global_affine_init - 1.)
         elif global_affine_type == 'SOFTPLUS':
@@ -238,58 +255,113 @@ class AllInOneBlock(InvertibleModule):
             raise ValueError('Global affine activation must be "SIGMOID", "SOFTPLUS" or "EXP"')
         self.global_scale = nn.Parameter(torch.ones(1, channels, 1, 1) * float(global_scale))
         self.global_offset = nn.Parameter(torch.zeros(1, channels, 1, 1))
-        # the reference draws this from numpy's global RNG (all_in_one_block.py:147): w[i, perm[i]] = 1
-        w = np.zeros((channels, channels))
-        for i, j in enumerate(np.random.permutation(channels)):
-            w[i, j] = 1.
-        self.w_perm = nn.Parameter(torch.FloatTensor(w).view(channels, channels, 1, 1), requires_grad=False)
-        self.w_perm_inv = nn.Parameter(torch.FloatTensor(w.T).view(channels, channels, 1, 1), requires_grad=False)
+        # the reference draws these from numpy's / scipy's global RNG (all_in_one_block.py:143-148)
+        if permute_soft:
+            from scipy.stats import special_ortho_group
+            w = special_ortho_group.rvs(channels)
+        else:
+            w = np.zeros((channels, channels))
+            for i, j in enumerate(np.random.permutation(channels)):
+                w[i, j] = 1.
+        if self.householder:
+            self.vk_householder = nn.Parameter(0.2 * torch.randn(self.householder, channels), requires_grad=True)
+            self.w_perm = None
+            self.w_perm_inv = None
+            self.w_0 = nn.Parameter(torch.FloatTensor(w), requires_grad=False)
+        else:
+            self.w_perm = nn.Parameter(torch.FloatTensor(w).view(channels, channels, 1, 1), requires_grad=False)
+            self.w_perm_inv = nn.Parameter(torch.FloatTensor(w.T).view(channels, channels, 1, 1), requires_grad=False)
         if subnet_constructor is None:
             raise ValueError("Please supply a callable subnet_constructor function or object (see docstring)")
         self.subnet = subnet_constructor(self.splits[0] + self.condition_channels, 2 * self.splits[1])
         self.last_jac = None
         self._tables = None
 
-    # ---- tiny parameter-side tables ([C] vectors; rebuilt when the parameters change)
+    def _construct_householder_permutation(self):
+        """w_0 . prod_k (I - 2 v_k v_k^T / v_k^T v_k), all_in_one_block.py:170-179 (a C x C host-side product)."""
+        w = self.w_0
+        for vk in self.vk_householder:
+            w = torch.mm(w, torch.eye(self.in_channels, device=w.device) - 2 * torch.ger(vk, vk) / torch.dot(vk, vk))
+        return w.view(self.in_channels, self.in_channels, 1, 1)
+
+    # ---- tiny parameter-side tables ([C] vectors, C x C mixes; rebuilt when the parameters change)
     def _prepare(self):
-        key = (self.w_perm._version, self.global_scale._version, self.global_offset._version, self.w_perm.data_ptr(),
-               self.global_scale.data_ptr())
+        wp = self._construct_householder_permutation().detach() if self.householder else self.w_perm.detach()
+        src = (self.vk_householder, self.w_0) if self.householder else (self.w_perm,)
+        key = (tuple(t._version for t in src), tuple(t.data_ptr() for t in src), self.global_scale._version,
+               self.global_offset._version, self.global_scale.data_ptr(), ops.pack_epoch())
         if self._tables is None or self._tables[0] != key:
-            w = self.w_perm.detach()[:, :, 0, 0]
-            if not bool(((w == 0) | (w == 1)).all()) or not bool((w.sum(0) == 1).all() and (w.sum(1) == 1).all()):
-                raise NotImplementedError("AllInOneBlock: w_perm is not a hard permutation matrix")
-            perm = w.argmax(1).contiguous()                     # fwd: out[:, i] = v[:, perm[i]]
-            perm_inv = w.t().argmax(1).contiguous()             # rev: out[:, i] = x[:, perm_inv[i]]
+            w = wp[:, :, 0, 0]
+            hard = bool(((w == 0) | (w == 1)).all()) and bool((w.sum(0) == 1).all() and (w.sum(1) == 1).all())
+            if hard:
+                mix = (w.argmax(1).contiguous(), w.t().argmax(1).contiguous())   # fwd: out[:, i] = v[:, perm[i]]; rev: perm_inv
+            else:      # dense mix: y = conv1x1(x, w) / conv1x1(x, w^T) (all_in_one_block.py:191-204)
+                mix = (ops.pack_conv_weight(wp.contiguous()), ops.pack_conv_weight(wp.transpose(0, 1).contiguous()))
             g = self.global_scale.detach().reshape(-1)
-            if self.global_affine_type == 'SOFTPLUS':
+            if self.GIN:
+                scale = torch.ones_like(g)                                        # :183-185
+            elif self.global_affine_type == 'SOFTPLUS':
                 scale = 0.1 * torch.nn.functional.softplus(g, beta=0.5)
             elif self.global_affine_type == 'SIGMOID':
                 scale = 10 * torch.sigmoid(g - 2.)
             else:
                 scale = torch.exp(g)
-            self._tables = (key, perm, perm_inv, scale.contiguous(), self.global_offset.detach().reshape(-1).contiguous(),
+            self._tables = (key, hard, mix, scale.contiguous(), self.global_offset.detach().reshape(-1).contiguous(),
                             torch.log(scale).sum().to(torch.float64))
         return self._tables[1:]
 
+    def _mix(self, x, hard, mix, inverse):
+        """x . w_perm (inverse=False) or x . w_perm_inv: a gather for hard permutations, a 1x1 conv otherwise."""
+        if hard:
+            return ops.gather(x, mix[1] if inverse else mix[0], 1)
+        return ops.conv2d(x, mix[1] if inverse else mix[0])
+
     def forward(self, x, c=[], rev=False, jac=True):
-        perm, perm_inv, scale, offset, log_scale_sum = self._prepare()
+        hard, mix, scale, offset, log_scale_sum = self._prepare()
         x0 = x[0]
         l1, l2 = self.splits
-        n_pix = x0.shape[2] * x0.shape[3]
+        B, _, H, W = x0.shape
+        n_pix = H * W
         acc = new_logdet(x0)
-        if rev:
-            v = ops.channel_affine(x0, scale, offset, inverse=True, perm_in=perm_inv)       # all_in_one_block.py:191-193
-            x1, x2 = v[:, :l1], v[:, l1:]
-            s_raw, t, _ = subnet_st(self.subnet, [x1, *c] if self.conditional else [x1], l2)
-            st = ops.stage(s_raw, t, "TANH", self.clamp, pre_scale=0.1)                     # `a *= 0.1`, :213
-            ops.affine(x2, st, True, logdet=acc, out=x2)
-            out = v
+        if rev:                                                                    # :191-193
+            if hard:
+                v = ops.channel_affine(x0, scale, offset, inverse=True, perm_in=mix[1])
+            else:
+                v = ops.channel_affine(self._mix(x0, hard, mix, True), scale, offset, inverse=True)
+        elif self.reverse_pre_permute:                                             # :198-204
+            v = self._mix(x0, hard, mix, True)
         else:
-            x1, x2 = x0[:, :l1], x0[:, l1:]
-            s_raw, t, _ = subnet_st(self.subnet, [x1, *c] if self.conditional else [x1], l2)
-            u = ops.concat_channels([x1, x2])
-            ops.affine(x2, ops.stage(s_raw, t, "TANH", self.clamp, pre_scale=0.1), False, logdet=acc, out=u[:, l1:])
-            out = ops.channel_affine(u, scale, offset, inverse=False, perm_out=perm)        # :194-196
+            v = x0
+        x1, x2 = v[:, :l1], v[:, l1:]
+        parts = [x1, *c] if self.conditional else [x1]
+        u = v if (rev or self.reverse_pre_permute) else ops.concat_channels([x1, x2])   # a tensor we own: x2 half is overwritten
+        fused = (not self.GIN and hasattr(self.subnet, "couple") and
+                 self.subnet.couple(parts, x2, u[:, l1:], "TANH", self.clamp, 0.1, rev, acc))   # `a *= 0.1`, :213
+        if not fused:
+            s_raw, t, _ = subnet_st(self.subnet, parts, l2)
+            st = ops.stage(s_raw, t, "TANH", self.clamp, pre_scale=0.1)
+        if fused:
+            pass
+        elif self.GIN:
+            # s <- s - mean_{C,H,W}(s) per sample (:218-219): sum s with one reduction pass (affine of a zero input), then the
+            # plain affine and a per-sample factor exp(-+mean) on the coupled half; log-det of the coupling is 0
+            ssum = new_logdet(x0)
+            ops.affine(None, st, False, shape=(B, l2, H, W), logdet=ssum)
+            m = (ssum / float(l2 * n_pix)).to(torch.float32)
+            tab = torch.exp(m if rev else -m).view(B, 1).expand(B, l2).contiguous()
+            if rev:
+                u = ops.concat_channels([x1, ops.scale_channels(ops.affine(x2, st, True), tab)])
+            else:
+                ops.affine(ops.scale_channels(x2, tab), st, False, out=u[:, l1:])
+        else:
+            ops.affine(x2, st, rev, logdet=acc, out=u[:, l1:])
+        if rev:
+            out = self._mix(u, hard, mix, False) if self.reverse_pre_permute else u   # :262-263
+        else:
+            if hard:
+                out = ops.channel_affine(u, scale, offset, inverse=False, perm_out=mix[0])     # :194-196
+            else:
+                out = self._mix(ops.channel_affine(u, scale, offset, inverse=False), hard, mix, False)
         acc = acc + (-1) ** int(rev) * n_pix * log_scale_sum
         return (out,), as_jac(acc)
 

@@ -38,6 +38,11 @@ class ConvOpts(C.Structure):
                 ("in_add_bs", C.c_int64), ("upshuffle2", C.c_int)]
 
 
+class Couple(C.Structure):
+    _fields_ = [("x", c_f32p), ("y", c_f32p), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("n", C.c_int), ("clamp_kind", C.c_int),
+                ("clamp", C.c_float), ("pre_scale", C.c_float), ("rev", C.c_int), ("logdet", c_f64p)]
+
+
 # name -> (restype, argtypes); must list EVERY function declared in include/cwfa_hip.h (tests/test_boundary.py checks)
 i, i64, f, d, p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
 SIGNATURES = {
@@ -95,6 +100,8 @@ SIGNATURES = {
     "cwfa_conv3x3_split_packed_bytes": (i64, [i, i]),
     "cwfa_conv3x3_split_pack_f32": (i, [p, p, i, i, p]),
     "cwfa_conv3x3_split_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_couple_rows": (i, [i, p]),
+    "cwfa_conv3x3_split_couple_f32": (i, [p, p, p, i, i, i, i, i64, C.POINTER(Couple), p]),
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),
     "cwfa_subnet_layer_split_pack_f32": (i, [p, p, p, p]),
     "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, p]),

@@ -53,6 +53,7 @@ struct SParams {
     int B, Cin, H, W, Cout, nchunks, nsteps, tiles_x;
     int64_t x_bs, y_bs;
     cwfa_conv_opts o;
+    cwfa_couple cp;             // EPI_COUPLE only
 };
 
 template <int K>
@@ -94,7 +95,17 @@ __device__ __forceinline__ float act_of(float v, float alpha) {
 // byte offset of the B fragments of tap t in buffer `buf`, relative to the lane base
 __host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XB + ((tap / 3) * XC + tap % 3) * 16; }
 
-enum { EPI_RUNTIME = -1 };
+enum { EPI_RUNTIME = -1, EPI_COUPLE = -2 };
+
+// the soft clamp of the coupling blocks (coupling_layers.py:50-60; same expressions as csrc/elementwise.hip)
+__device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
+    switch (kind) {
+        case CWFA_CLAMP_ATAN: return clamp * (0.636f * atanf(a));
+        case CWFA_CLAMP_TANH: return clamp * tanhf(a);
+        case CWFA_CLAMP_SIGMOID: return clamp * (2.f * (1.f / (1.f + expf(-a)) - 0.5f));
+        default: return clamp * a;
+    }
+}
 
 // ADD: a second tensor is added on load (UNet skip); ACT1: compile-time activation of the common epilogues (bias -> ACT1),
 // EPI_RUNTIME = whatever cwfa_conv_opts says (bias -> act -> + residual -> act2)
@@ -331,6 +342,63 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     const float alpha = p.o.prelu_alpha ? *p.o.prelu_alpha : 0.f;
     const int cwave = ct * CT + wm * MPW * 16;      // uniform: rides in the scalar offset
     const unsigned glane = (unsigned)(4 * g) * (unsigned)plane;                           // the lane group's channel offset
+    if constexpr (ACT1 == EPI_COUPLE) {
+        // The bank's rows were interleaved at pack time (cwfa_couple_rows) so that this lane holds s_j AND t_j of its pixels:
+        //   MPW = 1: pair j = 8 wm + 2 g + h  ->  s in register h, t in register h + 2 of the one m-tile
+        //   MPW = 2: pair j = 16 wm + 4 g + r ->  s in m-tile 0, t in m-tile 1, register r
+        // x / y descriptors end at channel n: pairs >= n read 0.0 and their stores are dropped (their s is 0: zero rows).
+        static_assert(MPW <= 2 && !ADD, "coupling epilogue: narrow tilings only");
+        constexpr int NP = MPW == 1 ? 2 : 4;                                       // pairs per lane and n-tile
+        const cwfa_couple& cp = p.cp;
+        const auto cx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cp.x + (int64_t)b * cp.x_bs), 0, cp.n * plane, 0x00020000);
+        const auto cy = __builtin_amdgcn_make_buffer_rsrc(cp.y + (int64_t)b * cp.y_bs, 0, cp.n * plane, 0x00020000);
+        const unsigned jlane = (unsigned)((MPW == 1 ? 2 : 4) * g) * (unsigned)plane;
+        const int jwave = wm * (MPW == 1 ? 8 : 16);
+        float bs[NP], bt[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int rs = k, rt = MPW == 1 ? k + 2 : 16 + k;                        // packed rows of s_j / t_j relative to cwave + 4g
+            bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + rs) * 4, 0));
+            bt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + rt) * 4, 0));
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = row0 + wn * 4 + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const bool ok = row < p.H && col < p.W;
+            const unsigned po = ok ? (unsigned)((row * p.W + col) * 4) + jlane : OOB;
+            float xv[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) xv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cx, po, (jwave + k) * plane, 0));
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const float sr = acc[0][nt][k] + bs[k];
+                float tr;
+                if constexpr (MPW == 1) tr = acc[0][nt][k + 2] + bt[k];
+                else tr = acc[MPW - 1][nt][k] + bt[k];
+                const float sv = soft_clamp(sr * cp.pre_scale, cp.clamp_kind, cp.clamp);
+                const float tv = tr * cp.pre_scale;
+                const float yv = cp.rev ? (xv[k] - tv) * expf(-sv) : expf(sv) * xv[k] + tv;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), cy, po, (jwave + k) * plane, 0);
+                ssum += ok ? sv : 0.f;
+            }
+            FENCE();
+        }
+        if (cp.logdet) {                                  // block sum -> one float64 atomic per block
+            const double ws = cwfa_wave_sum((double)ssum);
+            double* red = reinterpret_cast<double*>(lds);  // the operand buffers are dead (every wave passed the loop's last barrier)
+            __builtin_amdgcn_s_barrier();
+            if (lane == 0) red[wave] = ws;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) tot += red[w];
+                atomicAdd(&cp.logdet[b], cp.rev ? -tot : tot);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MPW; ++mt) {
         float bias[4];
@@ -426,6 +494,58 @@ int launch_epi(const SParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+// packed row r of a coupling bank <- source row of the torch weight [2n, Cin, 3, 3] (s_j = row j, t_j = row n + j), -1 = zero row
+static int couple_row_source(int n, int r) {
+    int j, which;
+    if (n <= 32) {                         // MPW = 1: row = 16 wm + 4 g + (h + 2 which), j = 8 wm + 2 g + h
+        const int wm = r >> 4, g = (r >> 2) & 3, q = r & 3;
+        j = 8 * wm + 2 * g + (q & 1);
+        which = q >> 1;
+    } else {                               // MPW = 2: row = 16 (2 wm + which) + 4 g + r4, j = 16 wm + 4 g + r4
+        const int wm = r >> 5;
+        which = (r >> 4) & 1;
+        j = 16 * wm + (r & 15);
+    }
+    return j < n ? which * n + j : -1;
+}
+
+extern "C" int cwfa_couple_rows(int n, int* rows) {
+    if (n <= 0 || n > 64) return -1;
+    const int total = n <= 32 ? 64 : 128;
+    if (rows)
+        for (int r = 0; r < total; ++r) rows[r] = couple_row_source(n, r);
+    return total;
+}
+
+extern "C" int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packed, const float* bias_rows, int B, int Cin, int H, int W,
+                                             int64_t x_bs, const cwfa_couple* cp, void* stream) {
+    CWFA_REQUIRE(B >= 0 && Cin > 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_conv3x3_split_couple_f32: bad size");
+    CWFA_REQUIRE(cp, CWFA_E_INVAL, "cwfa_conv3x3_split_couple_f32: null coupling descriptor");
+    CWFA_REQUIRE(cp->n > 0 && cp->n <= 64, CWFA_E_SHAPE, "cwfa_conv3x3_split_couple_f32: 1 <= n <= 64 (got %d)", cp->n);
+    if (B == 0 || H == 0 || W == 0) return CWFA_OK;
+    CWFA_REQUIRE(x && w_packed && cp->x && cp->y, CWFA_E_INVAL, "cwfa_conv3x3_split_couple_f32: null pointer");
+    CWFA_REQUIRE(cwfa_aligned16(w_packed), CWFA_E_ALIGN, "cwfa_conv3x3_split_couple_f32: packed weights must be 16-byte aligned");
+    CWFA_REQUIRE(cp->clamp_kind >= CWFA_CLAMP_NONE && cp->clamp_kind <= CWFA_CLAMP_SIGMOID, CWFA_E_INVAL,
+                 "cwfa_conv3x3_split_couple_f32: bad clamp kind %d", cp->clamp_kind);
+    SParams p{};
+    p.x = x; p.wp = w_packed; p.y = cp->y;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.x_bs = x_bs; p.y_bs = cp->y_bs;
+    p.Cout = cwfa_couple_rows(cp->n, nullptr);
+    p.o.bias = bias_rows;
+    p.cp = *cp;
+    p.nchunks = (Cin + 15) / 16;
+    p.nsteps = nsteps_of(Cin);
+    p.tiles_x = (W + TC - 1) / TC;
+    CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(cp->n + 64) * H * W * 4 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv3x3_split_couple_f32: one sample's input / active half must stay below 2 GiB");
+    CWFA_REQUIRE((int64_t)p.tiles_x * ((H + TR - 1) / TR) < (1ll << 31) && B <= 65535, CWFA_E_SHAPE,
+                 "cwfa_conv3x3_split_couple_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    const bool six = g_cwfa_split_products != 1;
+    if (p.Cout == 64) return six ? launch<1, true, false, EPI_COUPLE>(p, st) : launch<1, false, false, EPI_COUPLE>(p, st);
+    return six ? launch<2, true, false, EPI_COUPLE>(p, st) : launch<2, false, false, EPI_COUPLE>(p, st);
+}
 
 extern "C" int64_t cwfa_conv3x3_split_packed_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return -1;

@@ -126,7 +126,9 @@ class wavelet_flow_subnetwork(nn.Module):
         self.block72 = nn.Sequential(self.act(), cv(n, self.c_out, k))
 
     # ---- HIP path
-    def _stack(self, u, conv_in, conv_out, out=None):
+    def _stack(self, u, conv_in, conv_out, out=None, couple=None):
+        """``couple`` = (x, out, clamp_kind, clamp, pre_scale, rev, logdet): the last convolution applies the coupling to
+        ``x`` from its accumulators (ops.conv3x3_couple) instead of writing [s_raw | t]."""
         if self.conv_type is not nn.Conv2d:
             raise NotImplementedError("3-D sub-networks are not used by CWFA (every graph uses the 2-D subclasses)")
         P = self._packed.get
@@ -142,7 +144,33 @@ class wavelet_flow_subnetwork(nn.Module):
                 continue
             h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")
             b = ops.conv2d(h, P(blk[2]), bias=blk[2].bias, residual=b, act2="elu")   # ELU = block3 / block5 / block7x[0]
+        if couple is not None:
+            return ops.conv3x3_couple(b, self._couple_bank(conv_out), *couple)
         return ops.conv2d(b, P(conv_out), bias=conv_out.bias, out=out)
+
+    def _couple_bank(self, conv):
+        w, bias = conv.weight, conv.bias
+        hit = self._panels.get(("c", id(conv)))
+        if hit is not None:
+            pc = hit[0]
+            stale = (pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch() or
+                     (bias is not None and (pc.version1 != bias._version or pc.src_ptr1 != bias.data_ptr())))
+        if hit is None or stale:
+            hit = self._panels[("c", id(conv))] = ops.pack_couple_weight(w, bias)
+        return hit
+
+    def couple(self, parts, x, out, clamp_kind, clamp, pre_scale, rev, logdet):
+        """The whole coupling ``out = A(x | net(cat(parts)))`` with s, t kept in the accumulators of the last convolution
+        (coupling_layers.py:87-110; all_in_one_block.py:206-224).  Returns False when this form does not apply (precision
+        mode without the split-bf16 kernel, the ``_first`` variant, more than 64 active channels) -- the caller then takes
+        affine_parts + ops.affine."""
+        n = x.shape[1]
+        if (not self.normal or not ops.couple_fused() or self.conv_type is not nn.Conv2d or self.c_out != 2 * n or n > 64
+                or clamp_kind is None or (max(self.n_ch, n) + 64) * x.shape[2] * x.shape[3] * 4 >= 2 ** 31):
+            return False
+        u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+        self._stack(u, self.block12, self.block72[1], couple=(x, out, clamp_kind, clamp, pre_scale, rev, logdet))
+        return True
 
     def _split3(self, conv3, conv1):
         w, w1 = conv3.weight, conv1.weight

@@ -428,6 +428,70 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
     return out
 
 
+def pack_couple_weight(w, bias):
+    """Last convolution of a coupling sub-network, [2n,Cin,3,3] (+ bias [2n]): rows interleaved (cwfa_couple_rows) so that
+    s_j and t_j of a pixel land in the same lane of the split-bf16 kernel, whose epilogue then applies the coupling."""
+    L = _lib.lib()
+    w = _dev(w, "weight").detach()
+    n2, cin, ks, kw = w.shape
+    if ks != 3 or kw != 3 or n2 % 2 or n2 // 2 > 64:
+        raise ValueError(f"pack_couple_weight: a [2n,Cin,3,3] bank with n <= 64 is needed, got {tuple(w.shape)}")
+    n = n2 // 2
+    total = L.cwfa_couple_rows(n, None)
+    rows_c = (C.c_int * total)()
+    L.cwfa_couple_rows(n, rows_c)
+    rows = torch.tensor(list(rows_c), dtype=torch.int64, device=w.device)
+    live = (rows >= 0)
+    wr = torch.zeros((total, cin, 3, 3), dtype=torch.float32, device=w.device)
+    wr[live] = w[rows[live]]
+    br = torch.zeros(total, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        br[live] = _dev(bias, "bias").detach()[rows[live]]
+    packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(total, cin), dtype=torch.uint8, device=w.device)
+    check(L.cwfa_conv3x3_split_pack_f32(_p(wr), _p(packed), total, cin, _stream()), "conv3x3_split_pack (coupling bank)")
+    pc = PackedConv(packed, n2, cin, 3, False, w._version, w.data_ptr(), split=True)
+    pc.version1, pc.src_ptr1 = (bias._version, bias.data_ptr()) if bias is not None else (None, None)
+    return pc, br
+
+
+def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet=None):
+    """out = coupling(x | s, t) with [s_raw | t] = conv3x3(u) + bias taken from the accumulators of the convolution (they never
+    reach memory).  ``x`` / ``out``: the active half [B,n,H,W] (channel-slice views allowed; ``out`` may be ``x``)."""
+    L = _lib.lib()
+    pc, br = pc_bias
+    u, ubs = planes(u, "u")
+    B, Cin, H, W = u.shape
+    n = pc.cout // 2
+    if Cin != pc.cin:
+        raise ValueError(f"conv3x3_couple: input has {Cin} channels, filter bank expects {pc.cin}")
+    x2, xbs = planes(x, "x")
+    o2, obs = planes(out, "out")
+    if tuple(x.shape) != (B, n, H, W) or tuple(out.shape) != (B, n, H, W) or o2.data_ptr() != out.data_ptr():
+        raise ValueError("conv3x3_couple: x / out must be [B,n,H,W] views with contiguous planes")
+    cp = _lib.Couple()
+    cp.x, cp.y, cp.x_bs, cp.y_bs, cp.n = x2.data_ptr(), out.data_ptr(), xbs, obs, n
+    cp.clamp_kind, cp.clamp, cp.pre_scale, cp.rev = _lib.CLAMP[clamp_kind], float(clamp), float(pre_scale), int(bool(rev))
+    if logdet is not None:
+        cp.logdet = logdet.data_ptr()
+    rec = conv_event_sink
+    if rec is not None:
+        key = (3, Cin, pc.cout, H, W, B, "||||couple+split", False)
+        if rec.want(key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+    check(L.cwfa_conv3x3_split_couple_f32(_p(u), _p(pc.packed), _p(br), B, Cin, H, W, ubs, C.byref(cp), _stream()),
+          "conv3x3_split_couple")
+    if rec is not None and rec.want(key):
+        e1.record()
+        rec.add(key, e0, e1)
+    return out
+
+
+def couple_fused():
+    """True when the coupling epilogue is available in the active precision mode (split / bf16: the split-bf16 3x3 kernel)."""
+    return _split_bf16 >= 2
+
+
 SPLIT_3X3_MIN_COUT = 33     # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2
 conv_event_sink = None      # object with want(key)->bool and add(key, start_event, end_event); set by bench.py only
 

@@ -274,6 +274,29 @@ int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, float* y, int B
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
 
+/* The LAST convolution of a coupling sub-network (3x3, 64 -> 2n channels: [s_raw | t], networks.py:633-638) with the affine
+ * coupling applied from its accumulators -- s and t never reach memory:
+ *     fwd:  y = x * exp(s) + t            rev:  y = (x - t) * exp(-s)            logdet[b] += (rev ? -1 : +1) * sum s
+ *     s = soft_clamp(pre_scale * s_raw), t <- pre_scale * t      (coupling_layers.py:50-60,87-110; all_in_one_block.py:206-224)
+ * x / y: the ACTIVE half [B,n,H,W] of the block (planes contiguous, batch strides x_bs / y_bs; may be the same tensor).
+ * The filter bank is packed with its rows interleaved so that s_j and t_j of a pixel land in the same lane:
+ *     cwfa_couple_rows(n, rows): rows[r] = source row (0..2n-1) of packed row r, or -1 (zero row), r < cwfa_couple_rows(n, NULL)
+ *     w' = w[rows] (zeros for -1), bias' likewise;  packed = cwfa_conv3x3_split_pack_f32(w', Cout = that row count)
+ * n <= 64.  logdet nullable (float64[B], accumulated). */
+typedef struct {
+    const float* x;
+    float* y;
+    int64_t x_bs, y_bs;
+    int n;                      /* channels of the active half = half the outputs of the bank                           */
+    int clamp_kind;             /* CWFA_CLAMP_*                                                                          */
+    float clamp, pre_scale;
+    int rev;
+    double* logdet;
+} cwfa_couple;
+int cwfa_couple_rows(int n, int* rows);
+int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packed, const float* bias_rows, int B, int Cin, int H, int W,
+                                  int64_t x_bs, const cwfa_couple* cp, void* stream);
+
 /* The fused sub-network layer  y = ELU(W1 . ELU(conv3x3(x, W3) + b3) + b1 + x), 64 channels (networks.py:624-631,660-665)
  * with BOTH convolutions on the split-bf16 core (three bf16 pieces per fp32 operand, six products, fp32 accumulation;
  * `split_products` = 1: plain bf16 operands), one persistent launch (csrc/conv_split_layer.hip).

@@ -229,7 +229,8 @@ def block_onesided(sd: SD, p: str, x: Tensor, c: Sequence[Tensor], rev: bool, cl
 
 def block_ai1(sd: SD, p: str, x: Tensor, c: Sequence[Tensor], rev: bool, gin: bool = False,
               clamp: float = 2.0) -> Tuple[Tensor, Tensor]:
-    """AllInOneBlock (hard permutation, SOFTPLUS global affine).  all_in_one_block.py:181-268.
+    """AllInOneBlock (stored permutation matrix -- hard or soft --, SOFTPLUS global affine).  all_in_one_block.py:181-268.
+    (Householder / reverse-permutation / SIGMOID / EXP variants are pinned on the GPU side directly by the g18 fixtures.)
 
     fwd: split [C-C//2, C//2]; a = 0.1*subnet(cat(x1,c)); x2 <- x2*exp(clamp*tanh(a_s)) + a_t; then
     (x*scale + offset) through the 0/1 1x1 conv w_perm; scale = 0.1*softplus_{beta=.5}(global_scale).
@@ -477,6 +478,24 @@ def inverse_pass(steps: Sequence[dict], low: Tensor, cond_input: Tensor, mean_ca
                           st.get("n_blocks", 4), st.get("use_perm", True))
         vols.append(up)
     return vols
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mean-volume cache and output step
+def mean_volume_cache(levels: Sequence[Tensor]) -> List[Tensor]:
+    """``[gt[0, ::2] - gt[0, 1::2] for gt in gt_cache]`` (CWFA.py:655): even minus odd depth planes of the first sample."""
+    return [gt[0, ::2] - gt[0, 1::2] for gt in levels]
+
+
+def denormalise_prediction(stored: Tensor, std_vols: Tensor, mean_vols: Tensor) -> Tensor:
+    """CWFA.py:1041: ``(stored[0] * 2**len(stored)) * std + mean`` (len = the batch length of the stored tensor)."""
+    return (stored[0] * 2 ** len(stored)) * std_vols + mean_vols
+
+
+def denormalise_ground_truth(gt: Tensor, std_vols: Tensor, mean_vols: Tensor) -> Tensor:
+    """CWFA.py:1037-1038: ``gt[0] * std + mean`` minus its minimum."""
+    v = gt[0] * std_vols + mean_vols
+    return v - v.min()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -387,6 +387,93 @@ def gen_topology():
          jac_rev=np.float64(float(jr)), **sd_arrays(m))
 
 
+def gen_ai1_options():
+    """G18: AllInOneBlock options outside CWFA's defaults: soft permutation, learned householder, reverse permutation,
+    GIN, SIGMOID / EXP global affine (all_in_one_block.py:122-196)."""
+    import torch
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(1818)
+    C, H, W, Cc = 6, 8, 10, 3
+
+    class Sub(torch.nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.c = torch.nn.Conv2d(cin, cout, 3, padding=1)
+
+        def forward(self, t):
+            return self.c(t)
+
+    cases = {"soft": dict(permute_soft=True), "house": dict(learned_householder_permutation=2),
+             "revperm": dict(reverse_permutation=True), "gin": dict(gin_block=True),
+             "sigmoid": dict(global_affine_type="SIGMOID", global_affine_init=0.7), "exp": dict(global_affine_type="EXP", global_affine_init=1.3),
+             "soft_rev_gin": dict(permute_soft=True, reverse_permutation=True, gin_block=True)}
+    for name, kw in cases.items():
+        torch.manual_seed(40)
+        np.random.seed(41)
+        m = Fm.AllInOneBlock([(C, H, W)], dims_c=[(Cc, H, W)], subnet_constructor=Sub, **kw)
+        with torch.no_grad():
+            m.global_offset.copy_(0.1 * torch.randn(m.global_offset.shape, generator=g))
+            m.global_scale.add_(0.3 * torch.randn(m.global_scale.shape, generator=g))
+        x = torch.randn(2, C, H, W, generator=g)
+        c = torch.randn(2, Cc, H, W, generator=g)
+        (yf,), jf = m((x.clone(),), c=[c], rev=False)
+        (yr,), jr = m((x.clone(),), c=[c], rev=True)
+        arrs = {k2: npy(v) for k2, v in m.state_dict().items()}
+        dump(f"g18_ai1_opt_{name}", x=npy(x), c=npy(c), y_fwd=npy(yf), y_rev=npy(yr), jac_fwd=npy(jf), jac_rev=npy(jr),
+             **{"sd/" + k2: v for k2, v in arrs.items()})
+
+
+def gen_cache_and_output():
+    """G19: the mean-volume cache (the detail bands of the forward pyramid of a mean volume, CWFA.py:646-655; stored as
+    {'mean_vol_gt_cache': [...]} by main.py:366-377) and the output de-normalisation of the evaluation branch
+    (CWFA.py:1035-1044, with its 2**len(...) factor).  The pyramid comes from the reference's evaluate_INN_forward; the two
+    post-processing expressions are the reference's lines applied to its tensors."""
+    import io
+    import torch
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    fresh_process_state(networks)
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(1919)
+    S, D, H, W = 3, 16, 12, 16
+    args = argparse.Namespace(INN_max_down_steps=S, force_all_steps_NF=0, n_depths=D, volume_side_size=H)
+    conv_inn, cond_nets = [], []
+    torch.manual_seed(23)
+    np.random.seed(5)
+    for ix in range(S - 1):
+        Cn = D // 2 ** (ix + 1)
+        cn, inns = networks.conditional_wavelet_flow(
+            [D, H, W], [1, 29, H, W], networks.wavelet_flow_subnetwork2D,
+            lambda: networks.cond_network(29, Cn, ix + 1, S, [], 4),
+            n_internal_ch=8, n_down_steps=ix + 1, use_permutations=True, block_type="CAT", n_blocks=4)
+        conv_inn.append(inns[ix].eval())
+        cond_nets.append(cn.eval())
+    conv_inn.append(None)
+    mean_vols_stack = torch.randn(1, D, H, W, generator=g) + 0.1 * torch.arange(D).view(1, D, 1, 1)
+    mean_vols, std_vols = torch.tensor(0.3), torch.tensor(1.7)
+    gt_volume = (mean_vols_stack - mean_vols) / std_vols                                   # CWFA.py:646
+    views = torch.rand(1, 29, H, W, generator=g)
+    stats = (torch.tensor(0.1), torch.tensor(1.3), mean_vols, std_vols, torch.tensor(0.0), torch.tensor(1.0))
+    _, gt_cache, _, _ = CWFA.evaluate_INN_forward(conv_inn[:S - 1], cond_nets, args, [args] * S, gt_volume.clone(), views, stats)   # :653
+    levels = [t for t in gt_cache if t is not None]
+    cache = [gt[0, ::2, ...] - gt[0, 1::2, ...] for gt in levels]                            # :655
+    buf = io.BytesIO()
+    torch.save({'mean_vol_gt_cache': [v.cpu() for v in cache]}, buf)                        # main.py:377
+    arrs = {"gt_volume": npy(gt_volume)}
+    arrs.update({f"level_{i}": npy(t) for i, t in enumerate(levels)})
+    arrs.update({f"cache_{i}": npy(t) for i, t in enumerate(cache)})
+    arrs["file_bytes"] = np.frombuffer(buf.getvalue(), dtype=np.uint8).copy()
+    dump("g19_meanvol", **arrs)
+    # output step: B = 2 stored volumes -> the factor is 2**2
+    stored0 = torch.randn(2, D, H, W, generator=g)
+    gt0 = torch.randn(2, D, H, W, generator=g)
+    vol_out = gt0[0] * std_vols + mean_vols                                                  # :1037
+    vol_out -= vol_out.min()                                                                 # :1038
+    vol_out_pred = (stored0[0] * 2 ** len(stored0)) * std_vols + mean_vols                   # :1041
+    dump("g19_denorm", stored0=npy(stored0), gt0=npy(gt0), mean_vols=npy(mean_vols), std_vols=npy(std_vols),
+         vol_out=npy(vol_out), vol_out_pred=npy(vol_out_pred))
+
+
 def gen_extract_views():
     """g12: the reference's XLFMDatasetFull.extract_views on small frames, windows clipped at every border."""
     import_reference()
@@ -582,9 +669,15 @@ if __name__ == "__main__":
         gen_step_grad()
     elif len(sys.argv) > 1 and sys.argv[1] == "topology":
         gen_topology()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ai1_options":
+        gen_ai1_options()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cache_output":
+        gen_cache_and_output()
     else:
         main()
         gen_topology()
+        gen_ai1_options()
+        gen_cache_and_output()
         gen_extract_views()
         gen_step_grad()
         gen_unet_grad()

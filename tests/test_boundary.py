@@ -58,6 +58,28 @@ def test_argument_validation_without_gpu(built_lib):
     assert L.cwfa_affine_f32(None, p, ctypes.byref(_lib.AffineStage()), 0, 0, 4, 4, 4, 0, 0, None, None, None) == 0
 
 
+def test_couple_row_interleaving(built_lib):
+    """cwfa_couple_rows: every source row of a [2n] coupling bank appears exactly once, s_j and t_j in the same 4-row lane
+    group (n <= 32) / the same row of two adjacent 16-row m-tiles (n > 32)."""
+    from cwfa_amd import _lib
+    L = _lib.lib()
+    assert L.cwfa_couple_rows(0, None) == -1 and L.cwfa_couple_rows(65, None) == -1
+    for n in (1, 3, 24, 32, 33, 48, 64):
+        total = L.cwfa_couple_rows(n, None)
+        assert total == (64 if n <= 32 else 128)
+        rows = (ctypes.c_int * total)()
+        assert L.cwfa_couple_rows(n, rows) == total
+        rows = list(rows)
+        assert sorted(r for r in rows if r >= 0) == list(range(2 * n))
+        for j in range(n):
+            rs, rt = rows.index(j), rows.index(n + j)
+            assert (rt == rs + 2 and rs % 4 < 2) if n <= 32 else (rt == rs + 16 and (rs // 16) % 2 == 0)
+    assert L.cwfa_conv3x3_split_couple_f32(None, None, None, 1, 8, 8, 8, 0, None, None) == -1
+    cp = _lib.Couple()
+    cp.n = 65
+    assert L.cwfa_conv3x3_split_couple_f32(None, None, None, 1, 8, 8, 8, 0, ctypes.byref(cp), None) == -2
+
+
 def test_ops_fail_loudly_on_cpu_tensors(built_lib):
     from cwfa_amd import ops
     from cwfa_amd.INN_utils import HaarTransform1D

@@ -300,7 +300,7 @@ def test_coupling_blocks_golden(name):
     assert_close(xr, fx["x"], 1e-5, "round trip")
 
 
-@pytest.mark.parametrize("name", ["g05_ai1_gin0_cond1", "g05_ai1_gin0_cond0"])
+@pytest.mark.parametrize("name", names("g05_ai1_"))
 def test_all_in_one_golden(name):
     from cwfa_amd import networks as N
     from cwfa_amd.FrEIA import modules as Fm
@@ -308,14 +308,77 @@ def test_all_in_one_golden(name):
     N.networks_n_chans = 8
     cond = fx["c"].size > 0
     blk = Fm.AllInOneBlock([tuple(fx["x"].shape[1:])], dims_c=[tuple(fx["c"].shape[1:])] if cond else [],
-                           subnet_constructor=N.wavelet_flow_subnetwork2D)
+                           subnet_constructor=N.wavelet_flow_subnetwork2D, gin_block="gin1" in name)
     blk.load_state_dict(sd_of(fx))
     blk = blk.eval().cuda()
     c = (cu(fx["c"]),) if cond else ()
     for rev, key in ((False, "fwd"), (True, "rev")):
         (y,), j = blk((cu(fx["x"]),), c=c, rev=rev)
         assert_close(y, fx["y_" + key], TOL, f"{name} y {key}")
-        assert_close(j, fx["jac_" + key], TOL, f"{name} jac {key}")
+        _assert_ai1_jac(j, fx["jac_" + key], "gin1" in name, f"{name} jac {key}")
+
+
+def _assert_ai1_jac(j, ref, gin, what):
+    """GIN: the log-det is sum(s - mean(s)) = 0; the reference returns its fp32 rounding noise (~1e-6, all_in_one_block.py:
+    218-224), the HIP path an exact 0 -> absolute bound instead of a relative one."""
+    if gin:
+        assert float((j.cpu().double() - torch.as_tensor(ref).double()).abs().max()) <= 1e-4, what
+    else:
+        assert_close(j, ref, TOL, what)
+
+
+def test_mean_volume_cache_and_output_step_golden():
+    """SURVEY.md 8f row 3 on the HIP path: mean-volume cache bands from the forward pyramid (CWFA.py:646-655; pyramid levels
+    through the fused forward chain with zero conditions as evaluate_INN_forward runs them) and the output step
+    (CWFA.py:1035-1044) -- bit-exact against the reference's own tensors."""
+    from cwfa_amd import CWFA, ops
+    fx = load_golden("g19_meanvol")
+    levels = [cu(fx[f"level_{i}"]) for i in range(3)]
+    for i, v in enumerate(CWFA.mean_volume_cache(levels)):
+        assert torch.equal(v.cpu(), T(fx[f"cache_{i}"])), i
+    lv = cu(fx["gt_volume"])
+    for i in range(1, 3):                                   # the low band of the depth Haar is the next level
+        y = ops.haar1d(lv, False)
+        lv = y[:, :y.shape[1] // 2].contiguous()
+        assert_close(lv, fx[f"level_{i}"], 2e-6, f"level {i}")
+    fx = load_golden("g19_denorm")
+    pred = CWFA.denormalise_prediction(cu(fx["stored0"]), T(fx["std_vols"]), T(fx["mean_vols"]))
+    assert torch.equal(pred.cpu(), T(fx["vol_out_pred"]))
+    gt = CWFA.denormalise_ground_truth(cu(fx["gt0"]), T(fx["std_vols"]), T(fx["mean_vols"]))
+    assert torch.equal(gt.cpu(), T(fx["vol_out"]))
+
+
+@pytest.mark.parametrize("name", names("g18_ai1_opt_"))
+def test_all_in_one_options_golden(name):
+    """AllInOneBlock outside CWFA's defaults (all_in_one_block.py:122-196): soft (SO(C)) permutation and learned householder
+    reflections as dense 1x1 mixes, reverse permutation, GIN, SIGMOID / EXP global affine."""
+    from cwfa_amd.FrEIA import modules as Fm
+    fx = load_golden(name)
+    kw = {"soft": dict(permute_soft=True), "house": dict(learned_householder_permutation=2),
+          "revperm": dict(reverse_permutation=True), "gin": dict(gin_block=True),
+          "sigmoid": dict(global_affine_type="SIGMOID", global_affine_init=0.7), "exp": dict(global_affine_type="EXP", global_affine_init=1.3),
+          "soft_rev_gin": dict(permute_soft=True, reverse_permutation=True, gin_block=True)}[name[len("g18_ai1_opt_"):]]
+
+    class Sub(torch.nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.c = torch.nn.Conv2d(cin, cout, 3, padding=1)
+            self._pc = None
+
+        def forward(self, t):
+            from cwfa_amd import ops
+            if self._pc is None:
+                self._pc = ops.pack_conv_weight(self.c.weight)
+            return ops.conv2d(t, self._pc, bias=self.c.bias)
+
+    blk = Fm.AllInOneBlock([tuple(fx["x"].shape[1:])], dims_c=[tuple(fx["c"].shape[1:])], subnet_constructor=Sub, **kw)
+    assert sorted(blk.state_dict()) == sorted(sd_of(fx))
+    blk.load_state_dict(sd_of(fx))
+    blk = blk.cuda()
+    for rev, key in ((False, "fwd"), (True, "rev")):
+        (y,), j = blk((cu(fx["x"]),), c=(cu(fx["c"]),), rev=rev)
+        assert_close(y, fx["y_" + key], TOL, f"{name} y {key}")
+        _assert_ai1_jac(j, fx["jac_" + key], "gin" in name, f"{name} jac {key}")
 
 
 def test_actnorm_golden():
@@ -398,6 +461,90 @@ def _step(name, fx):
     _, g = build_step(bt, ix)
     g.load_state_dict(sd_of(fx))
     return bt, g.eval().cuda()
+
+
+@pytest.mark.parametrize("name", [n for n in names("g04_") if n.split("_")[1] in ("GLOW", "ONESIDED")] + names("g05_ai1_gin0") +
+                         [n for n in names("g09_") if "GLOW" in n or "AI1" in n])
+def test_coupling_in_the_conv_epilogue_golden(name, monkeypatch):
+    """Split precision: the last convolution of the sub-network applies the coupling from its accumulators (s, t never reach
+    memory; cwfa_conv3x3_split_couple_f32) -- same golden vectors, same bound as the unfused path."""
+    from cwfa_amd import ops
+    fx = load_golden(name)
+    calls = []
+    real = ops.conv3x3_couple
+    monkeypatch.setattr(ops, "conv3x3_couple", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    ops.set_precision("split_bf16")
+    try:
+        if name.startswith("g04_"):
+            _, bname, cl = name.split("_")
+            blk = _block(bname, cl, fx)
+            x, c = cu(fx["x"]), (cu(fx["c"]),)
+        elif name.startswith("g05_"):
+            from cwfa_amd import networks as N
+            from cwfa_amd.FrEIA import modules as Fm
+            N.networks_n_chans = 8
+            cond = fx["c"].size > 0
+            blk = Fm.AllInOneBlock([tuple(fx["x"].shape[1:])], dims_c=[tuple(fx["c"].shape[1:])] if cond else [],
+                                   subnet_constructor=N.wavelet_flow_subnetwork2D)
+            blk.load_state_dict(sd_of(fx))
+            blk = blk.eval().cuda()
+            x, c = cu(fx["x"]), ((cu(fx["c"]),) if cond else ())
+        else:
+            bt, g = _step(name, fx)
+            c = [cu(fx["c0"]), cu(fx["c1"])]
+            (z, low), jf = g(cu(fx["x"]), c=c)
+            assert_close(z, fx["z"], TOL, "z")
+            assert_close(jf, fx["jac_fwd"], TOL, "jac fwd")
+            xr, jr = g([cu(fx["z"]), cu(fx["low"])], c=c, rev=True)
+            assert_close(xr, fx["x_rev"], TOL, "x_rev")
+            assert_close(jr, fx["jac_rev"], TOL, "jac rev")
+            assert len(calls) == (16 if bt == "GLOW" else 8), len(calls)
+            return
+        for rev, key in ((False, "fwd"), (True, "rev")):
+            (y,), j = blk((x.clone(),), c=c, rev=rev)
+            assert_close(y, fx["y_" + key], TOL, f"{name} y {key}")
+            assert_close(j, fx["jac_" + key], TOL, f"{name} jac {key}")
+        assert len(calls) == (4 if "GLOW" in name else 2), len(calls)
+    finally:
+        ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("cfg", [(1, 24, 64, 40, 72, "ATAN", 1.0, False), (2, 48, 64, 33, 50, "TANH", 0.1, True),
+                                 (1, 3, 16, 17, 31, "SIGMOID", 1.0, True), (1, 33, 40, 24, 64, "ATAN", 1.0, False),
+                                 (2, 64, 64, 16, 32, "NONE", 0.5, True)])
+def test_conv3x3_couple_vs_unfused(cfg):
+    """cwfa_conv3x3_split_couple_f32 against conv (fp64 torch) + the coupling formula, both row interleavings (n <= 32 / > 32),
+    ragged sizes, in place, log-det."""
+    from cwfa_amd import ops
+    B, n, cin, H, W, kind, pre, rev = cfg
+    g = torch.Generator().manual_seed(n + H)
+    w = torch.randn(2 * n, cin, 3, 3, generator=g) * (1.5 / (3 * cin ** 0.5))
+    bias = torch.randn(2 * n, generator=g) * 0.1
+    u = torch.randn(B, cin, H, W, generator=g)
+    x = torch.randn(B, n, H, W, generator=g)
+    a = torch.nn.functional.conv2d(u.double(), w.double(), bias.double(), padding=1) * pre
+    clamp = 1.7
+    sr = a[:, :n]
+    s = {"ATAN": lambda v: clamp * 0.636 * torch.atan(v), "TANH": lambda v: clamp * torch.tanh(v),
+         "SIGMOID": lambda v: clamp * 2. * (torch.sigmoid(v) - 0.5), "NONE": lambda v: clamp * v}[kind](sr)
+    t = a[:, n:]
+    ref = (x.double() - t) * torch.exp(-s) if rev else torch.exp(s) * x.double() + t
+    jref = (-1 if rev else 1) * s.sum(dim=(1, 2, 3))
+    ops.set_precision("split_bf16")
+    try:
+        bank = ops.pack_couple_weight(w.cuda(), bias.cuda())
+        full = torch.randn(B, n + 5, H, W, generator=g).cuda()          # the active half as a channel slice of a larger tensor
+        full[:, 5:] = x.cuda()
+        ld = torch.zeros(B, dtype=torch.float64, device="cuda")
+        out = torch.empty(B, n, H, W, device="cuda")
+        ops.conv3x3_couple(u.cuda(), bank, full[:, 5:], out, kind, clamp, pre, rev, logdet=ld)
+        assert_close(out, ref, 1e-5, "coupled output")
+        assert_close(ld, jref, 1e-5, "log-det")
+        head = full[:, :5].clone()
+        ops.conv3x3_couple(u.cuda(), bank, full[:, 5:], full[:, 5:], kind, clamp, pre, rev)          # in place, no log-det
+        assert torch.equal(full[:, 5:], out) and torch.equal(full[:, :5], head)
+    finally:
+        ops.set_precision("fp32")
 
 
 @pytest.mark.parametrize("name", names("g09_"))
@@ -682,6 +829,44 @@ def test_baseline_small_configs_inverse_vs_oracle(cfg):
     assert vols[-1].shape == (1, D, side, side)
     for i, (a, b) in enumerate(zip(vols, ref)):
         assert_close(a, b, TOL, f"{what}, level {i}")
+
+
+@pytest.mark.parametrize("block_type", ["GLOW", "AI1", "RNVP", "GIN"])
+def test_full_size_block_types_vs_oracle(block_type):
+    """The block types ``--INN_block_type`` selects besides CAT (networks.py:289-297; north_star names GLOW and AI1), at
+    FULL size: the finest flow step of the 512x512x96 configuration (48 flow channels, its condition net, 4 blocks,
+    permutations) forward (latent, log-det) and inverse against the CPU oracle, in fp32 and in the benchmark's split-bf16
+    precision.  These blocks' coefficients depend on the data, so the step runs block by block (halves written in place)."""
+    from cwfa_amd import CWFA, ops
+    from oracle import cwfa_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, block_type=block_type, with_lrnn=False, device="cuda")
+    gi, cn = conv_inn[0], cond_nets[0]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 96, 512, 512, generator=g)
+    views = torch.randn(1, 29, 512, 512, generator=g)
+    mean = 0.1 * torch.randn(1, 48, 512, 512, generator=g)
+    low = torch.randn(1, 48, 512, 512, generator=g)
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+    with torch.no_grad():
+        om_r = O.omega_net(cpu(cn.state_dict()), views)
+        (z_r, low_r), ld_r = O.flow_step(cpu(gi.state_dict()), x, [om_r, mean], False, axes, block_type)
+        x_r, _ = O.flow_step(cpu(gi.state_dict()), (torch.zeros_like(low), low), [om_r, mean], True, axes, block_type)
+    for prec in ("fp32", "split_bf16"):
+        ops.set_precision(prec)
+        try:
+            with torch.no_grad():
+                om = cn(views.cuda())[-1]
+                Z, logdet = gi(x.cuda(), c=[om, mean.cuda()])
+                xi, _ = gi([torch.zeros_like(low).cuda(), low.cuda()], c=[om, mean.cuda()], rev=True)
+        finally:
+            ops.set_precision("fp32")
+        assert_close(Z[0], z_r, TOL, f"{block_type} {prec}: latent")
+        assert_close(Z[1], low_r, 5e-6, f"{block_type} {prec}: low band")
+        assert_close(logdet, ld_r, TOL, f"{block_type} {prec}: log-det")
+        assert_close(xi, x_r, TOL, f"{block_type} {prec}: inverse")
 
 
 def test_full_config3_inverse_vs_oracle():

@@ -171,3 +171,23 @@ def test_training_host_helpers_without_a_process_group():
         ops.set_precision("fp8")
     with pytest.raises(NotImplementedError):
         training.step_backward(type("G", (), {"_plan": None})(), None, [])
+
+
+def test_mean_volume_cache_file_round_trip(tmp_path):
+    """The cache file of main.py:377 as the reference wrote it (fixture bytes) loads with the weights-only loader, the
+    discovery rule of CWFA.py:637-640 finds it, and our writer produces a file the same loader reads back identically."""
+    import numpy as np
+    from conftest import load_golden
+    from cwfa_amd import CWFA
+    fx = load_golden("g19_meanvol")
+    p = tmp_path / "mean_vol_7Imgs_ds_3_train"
+    p.write_bytes(bytes(np.asarray(fx["file_bytes"], dtype=np.uint8)))
+    got = CWFA.load_mean_volume_cache(str(tmp_path), dataset_id=3, split="train")
+    assert got is not None and len(got) == 3
+    for i, v in enumerate(got):
+        assert torch.equal(v, torch.from_numpy(fx[f"cache_{i}"]))
+    assert CWFA.load_mean_volume_cache(str(tmp_path), dataset_id=4, split="train") is None
+    q = tmp_path / "mean_vol_7Imgs_ds_9_val"
+    CWFA.save_mean_volume_cache(str(q), got)
+    again = CWFA.load_mean_volume_cache(str(q))
+    assert all(torch.equal(a, b) for a, b in zip(again, got))

@@ -297,3 +297,17 @@ def test_concat_and_fixed1x1conv_golden():
     y, j = O.fixed1x1conv(T(fx["M"]), T(fx["x"]), True)
     assert_close(y, fx["y_rev"], 2e-5)
     assert abs(j - float(fx["jac_rev"])) <= 1e-5 * abs(float(fx["jac_rev"]))
+
+
+def test_mean_volume_cache_and_output_step_golden():
+    """the mean-volume cache (CWFA.py:646-655) from the pyramid levels and the output de-normalisation
+    (CWFA.py:1035-1044, 2**len factor)."""
+    fx = load_golden("g19_meanvol")
+    levels = [T(fx[f"level_{i}"]) for i in range(3)]
+    for i, v in enumerate(O.mean_volume_cache(levels)):
+        assert torch.equal(v, T(fx[f"cache_{i}"]))
+    for i, lv in enumerate(O.pyramid_forward(T(fx["gt_volume"]), 2)):
+        assert_close(lv, fx[f"level_{i}"], 2e-6)
+    fx = load_golden("g19_denorm")
+    assert torch.equal(O.denormalise_prediction(T(fx["stored0"]), T(fx["std_vols"]), T(fx["mean_vols"])), T(fx["vol_out_pred"]))
+    assert torch.equal(O.denormalise_ground_truth(T(fx["gt0"]), T(fx["std_vols"]), T(fx["mean_vols"])), T(fx["vol_out"]))
