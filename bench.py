@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--no-experiment", action="store_true", help="skip the extra measurements after the timed region")
     ap.add_argument("--split3x3-min", type=int, default=None, help="(tuning) smallest output-channel count of a 3x3 bank that takes "
                     "the split-bf16 kernel in split / bf16 precision (library default: ops.SPLIT_3X3_MIN_COUT)")
+    ap.add_argument("--no-couple-epilogue", action="store_true", help="(ablation, block types other than CAT) sub-networks write "
+                    "[s | t] and a separate affine launch applies the coupling")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -180,6 +182,8 @@ def main():
         global WINO2D_MIN
         WINO2D_MIN = a.wino2d
         ops.set_option("winograd_2d", a.wino2d)
+    if a.no_couple_epilogue:
+        ops.COUPLE_EPILOGUE = False
     if a.split3x3_min is not None:
         ops.SPLIT_3X3_MIN_COUT = a.split3x3_min
     PREC = {"split": "split_bf16", "fp32": "fp32", "bf16": "bf16"}

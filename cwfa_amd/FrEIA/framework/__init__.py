@@ -387,9 +387,74 @@ class _CatStepPlan:
         return tuple(outs), (acc.to(torch.float32) if jac else None)
 
 
+class _MixedStepPlan(_CatStepPlan):
+    """The same step graph with data-dependent coupling blocks (GLOW / RNVP / GIN / NICE / one-sided / AllInOne,
+    networks.py:305-366 with ``block_type`` != 'CAT') between the permutations.
+
+    ``chain`` additionally holds ('blk', node) entries.  The run of permutations / ConditionalAffineTransforms next to the
+    Haar transform -- forward: [first CAT, permutation]; the reference builds every step with this prefix, networks.py:
+    321-333 -- goes through ONE fused chain launch together with Haar1D and Split (ops.chain_fwd / chain_inv, exactly as in
+    the CAT plan); the blocks after it run as their own modules: each sub-network applies its coupling in the epilogue of
+    its last convolution (s, t never reach memory, halves written in place into the block's output), and the permutation
+    in front of a block is one gather launch."""
+
+    def __init__(self, graph, chain, flow_out_idx, low_out_idx):
+        super().__init__(graph, chain, flow_out_idx, low_out_idx)
+        first_blk = next(i for i, (k, _) in enumerate(chain) if k == "blk")
+        self.fused, self.rest = chain[:first_blk], chain[first_blk:]
+        self._sub = _CatStepPlan(graph, self.fused, flow_out_idx, low_out_idx)      # stage lists of the fused prefix
+
+    def _walk_rest(self, v, cond_of, rev, acc):
+        """The block part of the chain, module by module (forward order, or reversed)."""
+        for kind, obj in (reversed(self.rest) if rev else self.rest):
+            if kind == "perm":
+                (v,), _ = obj((v,), rev=rev)
+                continue
+            c = tuple(cond_of[cn] for cn in obj.conditions)
+            (v,), j = obj.module((v,), c=c, rev=rev, jac=acc is not None) if len(c) else obj.module((v,), rev=rev, jac=acc is not None)
+            if acc is not None and torch.is_tensor(j):
+                acc += j.to(torch.float64)
+            elif acc is not None and j:
+                acc += float(j)
+        return v
+
+    def run(self, x_or_z, c, rev, sumsq=None, jac=True):
+        g = self.graph
+        cond_of = dict(zip(g.condition_nodes, c))
+        first = next(t for t in x_or_z if t is not None)
+        acc = torch.zeros(first.shape[0], dtype=torch.float64, device=first.device) if jac else None
+        stages, pending = self._sub._stages(cond_of, rev)
+        if rev:
+            z, low = x_or_z[self.flow_out_idx], x_or_z[self.low_out_idx]
+            if z is None:
+                z = torch.zeros_like(low)
+            v = self._walk_rest(z, cond_of, True, acc)
+            if pending is not None:
+                stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
+            tabs = self._composed(True, self._perms_of(stages), None, tuple(low.shape[1:]), low.device)
+            out = ops.chain_inv(v, low, stages, logdet=acc, tables=tabs)
+            res = out if not g.force_tuple_output else (out,)
+            return res, (acc.to(torch.float32) if jac else None)
+        final_perm = None
+        if pending is not None:
+            if pending[1] == 1:
+                final_perm = pending[0]
+            else:
+                stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
+        shp = (first.shape[1] // 2, first.shape[2], first.shape[3])
+        tabs = self._composed(False, self._perms_of(stages), final_perm, shp, first.device)
+        v, low = ops.chain_fwd(first, stages, final_perm, logdet=acc, tables=tabs)
+        z = self._walk_rest(v, cond_of, False, acc)
+        if sumsq is not None:
+            ops.affine(z, ops.stage(None, None), False, sumsq=sumsq, out=z)      # identity stage: one pass that adds ||Z||^2
+        outs = [None, None]
+        outs[self.flow_out_idx], outs[self.low_out_idx] = z, low
+        return tuple(outs), (acc.to(torch.float32) if jac else None)
+
+
 def _lower_cat_step(g: "GraphINN"):
     """Recognise the CWFA step graph; return a plan or None (-> generic walk)."""
-    from ..modules.coupling import ConditionalAffineTransform
+    from ..modules.coupling import ConditionalAffineTransform, _TwoSided, AffineCouplingOneSided, AllInOneBlock
     if len(g.in_nodes) != 1 or len(g.out_nodes) != 2:
         return None
     inner = [n for n in g.node_list if n.module is not None]
@@ -427,6 +492,8 @@ def _lower_cat_step(g: "GraphINN"):
             chain.append(("cat", node))
         elif hasattr(m, "table") and hasattr(m, "axis"):
             chain.append(("perm", m))
+        elif isinstance(m, (_TwoSided, AffineCouplingOneSided, AllInOneBlock)):
+            chain.append(("blk", node))
         else:
             return None
         cur, cur_idx = node, 0
@@ -440,9 +507,14 @@ def _lower_cat_step(g: "GraphINN"):
                 n, pending = n + 1, False
         return n + int(pending)
 
-    if max(n_stages(chain), n_stages(chain[::-1])) > ops._lib.CHAIN_MAX or not any(k == "cat" for k, _ in chain):
-        return None
     if len(inner) != 2 + len(chain):
+        return None
+    if any(k == "blk" for k, _ in chain):
+        head = chain[:next(i for i, (k, _) in enumerate(chain) if k == "blk")]
+        if max(n_stages(head), n_stages(head[::-1])) > ops._lib.CHAIN_MAX:
+            return None
+        return _MixedStepPlan(g, chain, g.out_nodes.index(flow_out), g.out_nodes.index(low_out))
+    if max(n_stages(chain), n_stages(chain[::-1])) > ops._lib.CHAIN_MAX or not any(k == "cat" for k, _ in chain):
         return None
     return _CatStepPlan(g, chain, g.out_nodes.index(flow_out), g.out_nodes.index(low_out))
 

@@ -487,9 +487,12 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
     return out
 
 
+COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
+
+
 def couple_fused():
     """True when the coupling epilogue is available in the active precision mode (split / bf16: the split-bf16 3x3 kernel)."""
-    return _split_bf16 >= 2
+    return COUPLE_EPILOGUE and _split_bf16 >= 2
 
 
 SPLIT_3X3_MIN_COUT = 33     # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2

@@ -561,7 +561,8 @@ def test_flow_step_golden(name):
     assert_close(jr, fx["jac_rev"], TOL, "jac rev")
     x0, _ = g([torch.zeros_like(z), cu(fx["low"])], c=c, rev=True)
     assert_close(x0, fx["x_rev_z0"], TOL, "x_rev from z=0")
-    if bt == "CAT":
+    assert g._plan is not None, "every CWFA step graph lowers to a plan"
+    if True:
         # the fused plan (z=None: never read) and the node-by-node walk agree with each other and the reference
         x0n, _ = g([None, cu(fx["low"])], c=c, rev=True)
         assert torch.equal(x0n, x0)
@@ -836,7 +837,9 @@ def test_full_size_block_types_vs_oracle(block_type):
     """The block types ``--INN_block_type`` selects besides CAT (networks.py:289-297; north_star names GLOW and AI1), at
     FULL size: the finest flow step of the 512x512x96 configuration (48 flow channels, its condition net, 4 blocks,
     permutations) forward (latent, log-det) and inverse against the CPU oracle, in fp32 and in the benchmark's split-bf16
-    precision.  These blocks' coefficients depend on the data, so the step runs block by block (halves written in place)."""
+    precision.  These blocks' coefficients depend on the data: the step runs on the mixed plan (Haar + Split + first CAT +
+    permutation in one chain launch; then block by block, halves written in place, in split precision with the coupling in
+    the epilogue of each sub-network's last convolution)."""
     from cwfa_amd import CWFA, ops
     from oracle import cwfa_oracle as O
     torch.manual_seed(0)
