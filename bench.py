@@ -248,7 +248,7 @@ def main():
 
     # BASELINE.json configs[3] / the metric's second half: forward NLL, batch-sharded, one all-reduce of the NLL sums
     fwd = None
-    if not a.no_experiment and not a.no_lrnn and a.block_type == "CAT":
+    if not a.no_experiment and not a.no_lrnn:
         try:
             fwd = forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_all, products)
         except Exception as exc:                    # noqa: BLE001  (after the timed region; must not cost the line)
@@ -355,7 +355,7 @@ def forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_al
     tot = sel.totals()
     dom = max(tot, key=lambda k: tot[k][0])
     chain_ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in chain)
-    chain_bytes = sum(4.0 * 14 * Bc * C * H * W for _, Bc, C, H, W, *_ in chain)   # x (2C) + s,t of 5 blocks (10C) + z, low (2C)
+    chain_bytes = sum(4.0 * (4 + 2 * ns) * Bc * C * H * W for _, Bc, C, H, W, ns, *_ in chain)   # x (2C) + s,t of the stages + z, low (2C)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -455,17 +455,19 @@ def dwt_roofline(ops, step, a, dev, reps=20):
         step()
     torch.cuda.synchronize()
     ops.chain_event_sink = None
-    rows = [(kind, B, C, H, W, e0.elapsed_time(e1)) for kind, B, C, H, W, _, _, e0, e1 in chain]
+    # algorithmic planes of C x H x W floats per launch: low band + (z if it is read) + s, t of every stage + the 2C output
+    rows = [(kind, B, C, H, W, e0.elapsed_time(e1), 1 + int(zr) + 2 * ns + 2) for kind, B, C, H, W, ns, zr, e0, e1 in chain]
     ms = sum(r[5] for r in rows)
-    nbytes = sum(4.0 * 13 * B * C * H * W for _, B, C, H, W, _ in rows)
+    nbytes = sum(4.0 * pl * B * C * H * W for _, B, C, H, W, _, pl in rows)
     big = [r for r in rows if r[2] == max(r2[2] for r2 in rows)]
     gbs = nbytes / (ms * 1e-3) / 1e9
+    big_bytes = 4.0 * big[0][6] * big[0][1] * big[0][2] * big[0][3] * big[0][4]
     out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-           "kernel": "chain_rows4_kernel<true> (in-path: inverse Haar1D + Split/cat + 5 x (gather, affine), one launch per flow step)",
+           "kernel": "chain_rows4_kernel<true> (in-path: inverse Haar1D + Split/cat + %d x (gather, affine), one launch per flow step)"
+                     % ((big[0][6] - 3) // 2),
            "bytes_per_volume": nbytes / 3 / a.batch, "us_per_volume": 1e3 * ms / 3 / a.batch, "launches_timed": len(rows),
-           "largest_level": {"bytes_per_launch": 4.0 * 13 * big[0][1] * big[0][2] * big[0][3] * big[0][4],
-                             "avg_launch_us": 1e3 * sum(r[5] for r in big) / len(big),
-                             "GBps": 4.0 * 13 * big[0][1] * big[0][2] * big[0][3] * big[0][4] / (sum(r[5] for r in big) / len(big) * 1e-3) / 1e9}}
+           "largest_level": {"bytes_per_launch": big_bytes, "avg_launch_us": 1e3 * sum(r[5] for r in big) / len(big),
+                             "GBps": big_bytes / (sum(r[5] for r in big) / len(big) * 1e-3) / 1e9}}
     levels = [a.depths // 2 ** n for n in range(4)]
     bufs = [torch.randn(1, d, a.side, a.side, device=dev) for d in levels]
     for b in bufs:
@@ -482,6 +484,22 @@ def dwt_roofline(ops, step, a, dev, reps=20):
     nb2 = sum(8.0 * b.numel() for b in bufs)
     out["standalone_haar"] = {"kernel": "haar1d_inv_kernel<4> (NOT launched by the path)", "achieved": nb2 / (ms2 * 1e-3) / 1e9, "unit": "GB/s",
                               "frac": nb2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_volume": nb2, "us_per_volume": 1e3 * ms2}
+    # the one-pass 2 x 2 x 2 Haar tile (cwfa_haar3d_*: depth Haar + spatial Haar of every band; API surface, the path itself
+    # transforms along depth only): forward + inverse of one 512x512x96 volume, 8 bytes per element and direction
+    vol = torch.randn(1, a.depths, a.side, a.side, device=dev)
+    coef = ops.haar3d(vol)
+    ops.haar3d(coef, True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        coef = ops.haar3d(vol)
+        ops.haar3d(coef, True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms3 = e0.elapsed_time(e1) / reps
+    nb3 = 2 * 8.0 * vol.numel()
+    out["haar3d_tile"] = {"kernel": "haar3d_fwd_kernel<2> + haar3d_inv_kernel<2> (NOT launched by the path)", "achieved": nb3 / (ms3 * 1e-3) / 1e9,
+                          "unit": "GB/s", "frac": nb3 / (ms3 * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes": nb3, "us": 1e3 * ms3}
     return out
 
 

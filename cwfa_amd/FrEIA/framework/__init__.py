@@ -204,7 +204,7 @@ class GraphINN(InvertibleModule):
         c = [] if c is None else list(c)
         if len(c) != len(self.condition_nodes):
             raise ValueError(f"Got {len(c)} conditions, but expected {len(self.condition_nodes)}.")
-        if self._plan is not None and not intermediate_outputs:
+        if self._plan is not None and not intermediate_outputs and not self._plan.needs_walk():
             return self._plan.run(x_or_z, c, rev, sumsq, jac)
         if any(t is None for t in x_or_z):
             raise ValueError("None (an all-zero latent) is only understood by fused step plans")
@@ -317,6 +317,11 @@ class _CatStepPlan:
         self.flow_out_idx, self.low_out_idx = flow_out_idx, low_out_idx
         self._tables = {}
 
+    def needs_walk(self):
+        """An ActNorm that still has to initialise itself from its first batch (invertible_resnet.py:45-66) needs its input
+        tensor: that call goes node by node."""
+        return any(k == "act" and obj.init_on_next_batch for k, obj in self.chain)
+
     def _composed(self, rev, perms, final_perm, shape, device):
         """Per-axis composition of the direction's gathers (ops.chain_tables), cached while the permutation parameters
         are unchanged."""
@@ -337,6 +342,10 @@ class _CatStepPlan:
                 if pending is not None:                                 # two permutations in a row: identity affine
                     stages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
                 pending = (obj.table(rev), obj.axis)
+            elif kind == "act":                                         # ActNorm: per-channel s, t (invertible_resnet.py:68-81)
+                perm, axis = pending if pending is not None else (None, 1)
+                stages.append(obj.chain_stage(perm=perm, axis=axis))
+                pending = None
             else:
                 c = [cond_of[cn] for cn in obj.conditions]
                 perm, axis = pending if pending is not None else (None, 1)
@@ -409,6 +418,11 @@ class _MixedStepPlan(_CatStepPlan):
         for kind, obj in (reversed(self.rest) if rev else self.rest):
             if kind == "perm":
                 (v,), _ = obj((v,), rev=rev)
+                continue
+            if kind == "act":
+                (v,), j = obj((v,), rev=rev)
+                if acc is not None:
+                    acc += j.to(torch.float64)
                 continue
             c = tuple(cond_of[cn] for cn in obj.conditions)
             (v,), j = obj.module((v,), c=c, rev=rev, jac=acc is not None) if len(c) else obj.module((v,), rev=rev, jac=acc is not None)
@@ -492,6 +506,8 @@ def _lower_cat_step(g: "GraphINN"):
             chain.append(("cat", node))
         elif hasattr(m, "table") and hasattr(m, "axis"):
             chain.append(("perm", m))
+        elif type(m).__name__ == "ActNorm" and hasattr(m, "chain_stage") and len(m.dims_in) == 3:
+            chain.append(("act", m))
         elif isinstance(m, (_TwoSided, AffineCouplingOneSided, AllInOneBlock)):
             chain.append(("blk", node))
         else:

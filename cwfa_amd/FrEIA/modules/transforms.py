@@ -281,6 +281,20 @@ class ActNorm(InvertibleModule):
             return [ops.channel_affine(x[0], es, bs, inverse=False)], j
         return [ops.channel_affine(x[0], es, bs, inverse=True)], -j
 
+    def chain_stage(self, perm=None, axis=1):
+        """This module as a stage of a fused step chain (GraphINN plan lowering): s = scale_c, t = bias_c, no clamp --
+        ``y = exp(s) x + t`` / ``(x - t) exp(-s)`` with log-det +-sum s.  The chain kernels read s, t per element, so the two
+        per-channel vectors are broadcast once per parameter version into [1,C,H,W] tables shared by the whole batch."""
+        key = (self.scale._version, self.bias._version, self.scale.data_ptr(), self.bias.data_ptr())
+        if getattr(self, "_chain_tabs", None) is None or self._chain_tabs[0] != key:
+            Cc, H, W = self.dims_in
+            s_tab = self.scale.detach().reshape(1, Cc, 1, 1).expand(1, Cc, H, W).contiguous()
+            t_tab = self.bias.detach().reshape(1, Cc, 1, 1).expand(1, Cc, H, W).contiguous()
+            self._chain_tabs = (key, s_tab, t_tab)
+        st, keep = ops.stage(self._chain_tabs[1], self._chain_tabs[2], "NONE", 1.0, perm=perm, axis=axis)
+        st.s_bs = st.t_bs = 0                           # every sample reads the same table
+        return st, keep
+
     def output_dims(self, input_dims):
         assert len(input_dims) == 1, "Can only use 1 input"
         return input_dims

@@ -53,6 +53,8 @@ SIGNATURES = {
     "cwfa_haar1d_inv_f32": (i, [p, p, p, i, i, i64, i64, i64, i64, p]),
     "cwfa_haar2d_fwd_f32": (i, [p, p, i, i, i, i, i, f, p]),
     "cwfa_haar2d_inv_f32": (i, [p, p, i, i, i, i, i, f, p]),
+    "cwfa_haar3d_fwd_f32": (i, [p, p, i, i, i, i, i, f, i64, p]),
+    "cwfa_haar3d_inv_f32": (i, [p, p, i, i, i, i, i, f, i64, p]),
     "cwfa_gather_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, p]),
     "cwfa_affine_f32": (i, [p, p, C.POINTER(AffineStage), i, i, i, i, i, i64, i64, p, p, p]),
     "cwfa_channel_affine_f32": (i, [p, p, p, p, i, p, p, i, i, i64, i64, i64, p]),

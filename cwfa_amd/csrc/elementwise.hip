@@ -176,6 +176,118 @@ extern "C" int cwfa_haar2d_inv_f32(const float* y, float* x, int B, int C, int H
     return haar2d_launch(false, y, x, B, C, H, W, order_by_wavelet, fac, stream);
 }
 
+// ------------------------------------------------------------------------------------------------ Haar 3-D (2 x 2 x 2 tiles)
+// The depth Haar (INN_utils.py:142-161) followed by the spatial Haar of every band (reshapes.py:273-300) in ONE pass:
+// y = haar2d(haar1d(x)), [B,D,H,W] -> [B,4D,H/2,W/2].  One thread = one depth pair x NP adjacent 2x2 patches = NP 2x2x2
+// tiles, kept in registers: 4 loads of 8*NP bytes, 8 stores of 4*NP bytes, every element read once and written once
+// (8 bytes per element; the two-launch composition moves 16).  The arithmetic is the composition's, operation by
+// operation ((e + o) * f, then ((p00 + p01) + p10) + p11 times fac), so the results are bit-identical to it.
+template <int NP>
+__global__ __launch_bounds__(256) void haar3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W,
+                                                         int obw, float fac, int64_t x_bs) {
+    typedef float vin_t __attribute__((ext_vector_type(2 * NP)));
+    typedef float vout_t __attribute__((ext_vector_type(NP)));
+    const int h2 = H / 2, w2 = W / 2, wq = w2 / NP;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)h2 * wq) return;
+    const int k = blockIdx.y, b = blockIdx.z, hy = (int)(i / wq), wx = (int)(i % wq) * NP;
+    const int64_t HW = (int64_t)H * W;
+    const float* pe = x + b * x_bs + (int64_t)(2 * k) * HW + (int64_t)(2 * hy) * W + 2 * wx;
+    const vin_t e0 = *reinterpret_cast<const vin_t*>(pe), e1 = *reinterpret_cast<const vin_t*>(pe + W);
+    const vin_t o0 = *reinterpret_cast<const vin_t*>(pe + HW), o1 = *reinterpret_cast<const vin_t*>(pe + HW + W);
+    const vin_t band[2][2] = {{(e0 + o0) * CWFA_INV_SQRT2_F, (e1 + o1) * CWFA_INV_SQRT2_F},      // low band rows 0, 1
+                              {(e0 - o0) * CWFA_INV_SQRT2_F, (e1 - o1) * CWFA_INV_SQRT2_F}};     // detail band
+    const int64_t plane = (int64_t)h2 * w2, pos = (int64_t)hy * w2 + wx;
+    float* py = y + (int64_t)b * 4 * D * plane + pos;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int c = hb * (D / 2) + k;                      // channel of the band in the depth-Haar layout (lo | hi)
+        const int c0 = obw ? c : 4 * c, cs = obw ? D : 1;
+        vout_t a, v1, v2, d;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const float p00 = band[hb][0][2 * q], p01 = band[hb][0][2 * q + 1], p10 = band[hb][1][2 * q], p11 = band[hb][1][2 * q + 1];
+            a[q] = (((p00 + p01) + p10) + p11) * fac;
+            v1[q] = (((p00 - p01) + p10) - p11) * fac;
+            v2[q] = (((p00 + p01) - p10) - p11) * fac;
+            d[q] = (((p00 - p01) - p10) + p11) * fac;
+        }
+        *reinterpret_cast<vout_t*>(py + (int64_t)(c0)*plane) = a;
+        *reinterpret_cast<vout_t*>(py + (int64_t)(c0 + cs) * plane) = v1;
+        *reinterpret_cast<vout_t*>(py + (int64_t)(c0 + 2 * cs) * plane) = v2;
+        *reinterpret_cast<vout_t*>(py + (int64_t)(c0 + 3 * cs) * plane) = d;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void haar3d_inv_kernel(const float* __restrict__ y, float* __restrict__ x, int D, int H, int W,
+                                                         int obw, float fac, int64_t x_bs) {
+    typedef float vin_t __attribute__((ext_vector_type(2 * NP)));
+    typedef float vout_t __attribute__((ext_vector_type(NP)));
+    const int h2 = H / 2, w2 = W / 2, wq = w2 / NP;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)h2 * wq) return;
+    const int k = blockIdx.y, b = blockIdx.z, hy = (int)(i / wq), wx = (int)(i % wq) * NP;
+    const int64_t HW = (int64_t)H * W, plane = (int64_t)h2 * w2, pos = (int64_t)hy * w2 + wx;
+    const float* py = y + (int64_t)b * 4 * D * plane + pos;
+    vin_t band[2][2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int c = hb * (D / 2) + k;
+        const int c0 = obw ? c : 4 * c, cs = obw ? D : 1;
+        const vout_t a = *reinterpret_cast<const vout_t*>(py + (int64_t)(c0)*plane) * fac;
+        const vout_t v1 = *reinterpret_cast<const vout_t*>(py + (int64_t)(c0 + cs) * plane) * fac;
+        const vout_t v2 = *reinterpret_cast<const vout_t*>(py + (int64_t)(c0 + 2 * cs) * plane) * fac;
+        const vout_t d = *reinterpret_cast<const vout_t*>(py + (int64_t)(c0 + 3 * cs) * plane) * fac;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            band[hb][0][2 * q] = ((a[q] + v1[q]) + v2[q]) + d[q];
+            band[hb][0][2 * q + 1] = ((a[q] - v1[q]) + v2[q]) - d[q];
+            band[hb][1][2 * q] = ((a[q] + v1[q]) - v2[q]) - d[q];
+            band[hb][1][2 * q + 1] = ((a[q] - v1[q]) - v2[q]) + d[q];
+        }
+    }
+    float* pe = x + b * x_bs + (int64_t)(2 * k) * HW + (int64_t)(2 * hy) * W + 2 * wx;
+    *reinterpret_cast<vin_t*>(pe) = (band[0][0] + band[1][0]) * CWFA_INV_SQRT2_F;
+    *reinterpret_cast<vin_t*>(pe + W) = (band[0][1] + band[1][1]) * CWFA_INV_SQRT2_F;
+    *reinterpret_cast<vin_t*>(pe + HW) = (band[0][0] - band[1][0]) * CWFA_INV_SQRT2_F;
+    *reinterpret_cast<vin_t*>(pe + HW + W) = (band[0][1] - band[1][1]) * CWFA_INV_SQRT2_F;
+}
+
+static int haar3d_launch(bool fwd, const float* a, float* b, int B, int D, int H, int W, int obw, float fac, int64_t x_bs,
+                         void* stream) {
+    const char* name = fwd ? "cwfa_haar3d_fwd_f32" : "cwfa_haar3d_inv_f32";
+    CWFA_REQUIRE(B >= 0 && D >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "%s: negative size", name);
+    if (B == 0 || D == 0 || H == 0 || W == 0) return CWFA_OK;
+    CWFA_REQUIRE(a && b, CWFA_E_INVAL, "%s: null pointer", name);
+    CWFA_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, CWFA_E_SHAPE, "%s: D=%d, H=%d, W=%d must be even", name, D, H, W);
+    CWFA_REQUIRE(D / 2 <= 65535 && B <= 65535, CWFA_E_SHAPE, "%s: grid too large (D/2=%d, B=%d)", name, D / 2, B);
+    const float* xin = fwd ? a : b;                         // the [B,D,H,W] side carries the batch stride
+    const float* yside = fwd ? b : a;
+    const bool np2 = W % 4 == 0 && x_bs % 4 == 0 && cwfa_aligned16(xin) && (reinterpret_cast<uintptr_t>(yside) & 7u) == 0;
+    const int64_t n = (int64_t)(H / 2) * (W / 2 / (np2 ? 2 : 1));
+    dim3 grid((unsigned)((n + 255) / 256), D / 2, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd) {
+        if (np2) hipLaunchKernelGGL(haar3d_fwd_kernel<2>, grid, dim3(256), 0, st, a, b, D, H, W, obw, fac, x_bs);
+        else hipLaunchKernelGGL(haar3d_fwd_kernel<1>, grid, dim3(256), 0, st, a, b, D, H, W, obw, fac, x_bs);
+    } else {
+        if (np2) hipLaunchKernelGGL(haar3d_inv_kernel<2>, grid, dim3(256), 0, st, a, b, D, H, W, obw, fac, x_bs);
+        else hipLaunchKernelGGL(haar3d_inv_kernel<1>, grid, dim3(256), 0, st, a, b, D, H, W, obw, fac, x_bs);
+    }
+    CWFA_LAUNCH_CHECK(name);
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_haar3d_fwd_f32(const float* x, float* y, int B, int D, int H, int W, int order_by_wavelet, float fac,
+                                   int64_t x_bs, void* stream) {
+    return haar3d_launch(true, x, y, B, D, H, W, order_by_wavelet, fac, x_bs, stream);
+}
+extern "C" int cwfa_haar3d_inv_f32(const float* y, float* x, int B, int D, int H, int W, int order_by_wavelet, float fac,
+                                   int64_t x_bs, void* stream) {
+    return haar3d_launch(false, y, x, B, D, H, W, order_by_wavelet, fac, x_bs, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ gathers
 struct Pos {
     int c, h, w;

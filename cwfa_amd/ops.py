@@ -98,6 +98,26 @@ def haar2d(x, rev, order_by_wavelet, fac):
     return out
 
 
+def haar3d(x, rev=False, order_by_wavelet=True, fac=0.5):
+    """The 2 x 2 x 2 Haar tile in one launch: fwd x[B,D,H,W] -> haar2d(haar1d(x)) [B,4D,H/2,W/2]; rev the inverse.
+    Bit-identical to the two-launch composition (``fac`` = haar2d's factor: 0.5 * rebalance)."""
+    L = _lib.lib()
+    if not rev:
+        x, xbs = planes(x, "x")
+        B, D, H, W = x.shape
+        out = torch.empty((B, 4 * D, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(L.cwfa_haar3d_fwd_f32(_p(x), _p(out), B, D, H, W, int(order_by_wavelet), float(fac), xbs, _stream()), "haar3d_fwd")
+        return out
+    y = _dev(x, "y").contiguous()
+    B, D4, h, w = y.shape
+    if D4 % 8:
+        raise ValueError(f"haar3d: {D4} channels are not 4 x an even depth")
+    out = torch.empty((B, D4 // 4, 2 * h, 2 * w), dtype=torch.float32, device=y.device)
+    check(L.cwfa_haar3d_inv_f32(_p(y), _p(out), B, D4 // 4, 2 * h, 2 * w, int(order_by_wavelet), float(fac), out.stride(0), _stream()),
+          "haar3d_inv")
+    return out
+
+
 def gather(x, perm, axis):
     L = _lib.lib()
     x, xbs = planes(x, "x")

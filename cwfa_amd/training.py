@@ -138,7 +138,7 @@ def step_backward(graph, gt, c, low=None, z=None, cond_weight=0.40984, loss_func
     Returns a dict: full_loss, nll, recon (mean), Z, xhat, cond_grads."""
     from .CWFA import allreduce_nll
     plan = getattr(graph, "_plan", None)
-    if plan is None or hasattr(plan, "rest"):            # no plan, or the mixed plan of a data-dependent block type
+    if plan is None or hasattr(plan, "rest") or any(k == "act" for k, _ in plan.chain):    # no plan / mixed plan / ActNorm stages
         raise NotImplementedError("step_backward: only conditional-affine (CAT) steps lowered to a chain plan are built")
     if loss_func not in ("L1", "L2"):
         raise NotImplementedError(f"step_backward: loss_func {loss_func!r} (L1 and L2 are built)")

@@ -79,6 +79,15 @@ int cwfa_haar2d_fwd_f32(const float* x, float* y, int B, int C, int H, int W, in
 int cwfa_haar2d_inv_f32(const float* y, float* x, int B, int C, int H, int W, int order_by_wavelet, float fac,
                         void* stream);
 
+/* 3-D Haar over 2 x 2 x 2 tiles in ONE pass: the depth Haar (INN_utils.py:142-161; lo | hi halves on the channel axis)
+ * followed by the spatial Haar of every band (reshapes.py:273-300), y = haar2d(haar1d(x)): x [B,D,H,W] (batch stride
+ * x_bs) <-> y [B,4D,H/2,W/2] (contiguous).  order_by_wavelet / fac as cwfa_haar2d_*; bit-identical to the two-launch
+ * composition; 8 bytes of traffic per element instead of 16. */
+int cwfa_haar3d_fwd_f32(const float* x, float* y, int B, int D, int H, int W, int order_by_wavelet, float fac, int64_t x_bs,
+                        void* stream);
+int cwfa_haar3d_inv_f32(const float* y, float* x, int B, int D, int H, int W, int order_by_wavelet, float fac, int64_t x_bs,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Permutations (index gathers)
  * ---------------------------------------------------------------------------------------------- */

@@ -105,6 +105,33 @@ def test_haar2d_then_haar1d_is_the_3d_tile():
     assert_close(a, b, 2e-6)
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 16, 16), (2, 6, 10, 14), (1, 4, 6, 20), (3, 2, 2, 2)])
+@pytest.mark.parametrize("obw", [True, False])
+def test_haar3d_is_the_two_launch_composition_bit_exact(shape, obw):
+    """cwfa_haar3d_*: one pass over 2x2x2 tiles == haar2d(haar1d(x)) bit for bit (both channel orders, W % 4 != 0 included),
+    against the oracle, and back."""
+    from cwfa_amd import ops
+    from oracle import cwfa_oracle as O
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    y = ops.haar3d(x.cuda(), False, obw, 0.5)
+    assert torch.equal(y, ops.haar2d(ops.haar1d(x.cuda(), False), False, obw, 0.5))
+    assert_close(y, O.haar2d(O.haar1d(x, False)[0], False, obw, 1.0)[0], 2e-6)
+    xr = ops.haar3d(y, True, obw, 0.5)
+    assert torch.equal(xr, ops.haar1d(ops.haar2d(y, True, obw, 0.5), True))
+    assert_close(xr, x, 2e-6)
+    big = torch.randn(shape[0], shape[1] + 2, shape[2], shape[3], device="cuda")         # channel-sliced input (batch stride)
+    assert torch.equal(ops.haar3d(big[:, 2:], False, obw, 0.5), ops.haar3d(big[:, 2:].contiguous(), False, obw, 0.5))
+
+
+def test_haar3d_full_size_round_trip():
+    from cwfa_amd import ops
+    x = torch.randn(1, 96, 512, 512, device="cuda")
+    y = ops.haar3d(x)
+    assert y.shape == (1, 384, 256, 256)
+    assert_close(ops.haar3d(y, True), x, 2e-6)
+    assert abs(float(y.double().pow(2).sum() / x.double().pow(2).sum()) - 1.0) < 1e-6       # orthonormal with fac = 0.5
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 @pytest.mark.parametrize("cfg", [
     # (B, Cin, H, W, Cout, ks)
@@ -507,6 +534,60 @@ def test_coupling_in_the_conv_epilogue_golden(name, monkeypatch):
         assert len(calls) == (4 if "GLOW" in name else 2), len(calls)
     finally:
         ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("block", ["CAT", "GLOW"])
+def test_actnorm_stays_in_the_step_plan(block):
+    """A step graph with ActNorm nodes (invertible_resnet.py:27-85; the reference keeps reset_ActNorm for such graphs,
+    networks.py:137-163) still lowers to a plan: ActNorm is a per-channel stage of the fused chain.  The first forward call
+    initialises the ActNorms from their input batch (node walk); afterwards plan == node walk in both directions."""
+    from cwfa_amd import networks as N, INN_utils
+    from cwfa_amd.FrEIA import framework as Ff, modules as Fm
+    N.networks_n_chans = 8
+    torch.manual_seed(3)
+    np.random.seed(3)
+    D, H, W, B = 8, 8, 64, 2
+    C_ = D // 2
+    nodes = [Ff.InputNode(D, H, W, name="input")]
+    nodes.append(Ff.Node(nodes[-1], INN_utils.HaarTransform1D, {"order_by_wavelet": True}, name="haar"))
+    split = Ff.Node(nodes[-1], Fm.Split, {"section_sizes": (C_, C_), "dim": 0}, name="split")
+    nodes.append(split)
+    cond = Ff.ConditionNode(C_, H, W, name="cond")
+    nodes.append(cond)
+    nodes.append(Ff.Node(split.out1, Fm.ConditionalAffineTransform, {"subnet_constructor": N.wavelet_flow_subnetwork2D},
+                         conditions=[cond], name="cat0"))
+    nodes.append(Ff.Node(nodes[-1], Fm.ActNorm, {}, name="an0"))
+    nodes.append(Ff.Node(nodes[-1], Fm.PermuteRandom, {"seed": 1}, name="p1"))
+    blk = Fm.ConditionalAffineTransform if block == "CAT" else Fm.GLOWCouplingBlock
+    nodes.append(Ff.Node(nodes[-1], blk, {"subnet_constructor": N.wavelet_flow_subnetwork2D}, conditions=[cond], name="b1"))
+    nodes.append(Ff.Node(nodes[-1], Fm.ActNorm, {}, name="an1"))
+    nodes.append(Ff.Node(nodes[-1], INN_utils.PermuteDim, {"seed": 2}, name="p2"))
+    nodes.append(Ff.OutputNode(nodes[-1], name="z"))
+    nodes.append(Ff.OutputNode(split.out0, name="low"))
+    g = Ff.GraphINN(nodes).cuda()
+    assert g._plan is not None and sum(k == "act" for k, _ in g._plan.chain) == 2
+    gen = torch.Generator().manual_seed(4)
+    x = (2.0 * torch.randn(B, D, H, W, generator=gen) + 0.5).cuda()
+    c = [torch.randn(B, C_, H, W, generator=gen).cuda()]
+    assert g._plan.needs_walk()
+    (z0, low0), j0 = g(x, c=c)                                   # data-dependent initialisation: node walk
+    assert not g._plan.needs_walk()
+    an = [m for m in g.module_list if isinstance(m, Fm.ActNorm)]
+    assert all(float(m.scale.abs().max()) > 0 for m in an)
+    (z, low), j = g(x, c=c)                                      # the plan
+    assert_close(z, z0, 1e-5, "plan vs walk: z")
+    assert torch.equal(low, low0)
+    assert_close(j, j0, 1e-5, "plan vs walk: log-det")
+    xr, jr = g([z, low], c=c, rev=True)
+    assert_close(xr, x, 1e-5, "round trip")
+    assert_close(jr, -j, 1e-5, "log-det of the inverse")
+    plan, g._plan = g._plan, None
+    try:
+        xw, jw = g([z, low], c=c, rev=True)
+    finally:
+        g._plan = plan
+    assert_close(xr, xw, 1e-5, "plan vs walk: inverse")
+    assert_close(jr, jw, 1e-5)
 
 
 @pytest.mark.parametrize("cfg", [(1, 24, 64, 40, 72, "ATAN", 1.0, False), (2, 48, 64, 33, 50, "TANH", 0.1, True),

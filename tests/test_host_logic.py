@@ -49,8 +49,11 @@ def test_step_graph_matches_reference(name):
         if type(m).__name__ == "AllInOneBlock":
             assert torch.equal(m.w_perm, ref_sd[f"module_list.{i}.w_perm"])
     g.load_state_dict(ref_sd)
-    # only the all-CAT step lowers to the fused chain plan
-    assert (g._plan is not None) == (bt == "CAT")
+    # every step graph lowers to a plan: all-CAT steps to ONE fused chain launch, the data-dependent block types to the mixed
+    # plan (fused Haar / Split / first CAT / permutation prefix + blocks with the coupling in the conv epilogue)
+    assert g._plan is not None and hasattr(g._plan, "rest") == (bt != "CAT")
+    if bt != "CAT":
+        assert [k for k, _ in g._plan.fused] == ["cat", "perm"] and sum(k == "blk" for k, _ in g._plan.rest) == 4
 
 
 def test_condition_net_layout_and_shared_prelu():
