@@ -63,6 +63,28 @@ __device__ __forceinline__ float cwfa_elu(float v) {
     const float e = __expf(v) - 1.0f;
     return v > 0.f ? v : e;
 }
+// atan for the soft clamp of the couplings (coupling_layers.py:52: 0.636 * atan(s / clamp) ...).  ocml's atanf is ~30 vector
+// instructions (an IEEE division in its range reduction); the fused chain kernels evaluate it five times per element and
+// were VALU-bound on it.  Here: r = |x| or 1/|x| (v_rcp_f32), atan(r) = r * P(r^2) with a degree-7 Chebyshev-interpolated
+// P on [0, 1], pi/2 - . for |x| > 1, sign restored: 15 instructions, absolute error <= 1.9e-7 (3 ulp at pi/2) over all x.
+__device__ __forceinline__ float cwfa_atan(float x) {
+    const float ax = fabsf(x);
+    const bool inv = ax > 1.0f;
+    const float r = inv ? __builtin_amdgcn_rcpf(ax) : ax;
+    const float t = r * r;
+    float p = -0.00455979211255908f;
+    p = fmaf(p, t, 0.023780519142746925f);
+    p = fmaf(p, t, -0.05882975459098816f);
+    p = fmaf(p, t, 0.09868865460157394f);
+    p = fmaf(p, t, -0.14003290235996246f);
+    p = fmaf(p, t, 0.19966961443424225f);
+    p = fmaf(p, t, -0.3333181142807007f);
+    p = fmaf(p, t, 0.9999998807907104f);
+    float a = p * r;
+    a = inv ? 1.57079632679489661923f - a : a;
+    return copysignf(a, x);
+}
+
 __device__ __forceinline__ float cwfa_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float cwfa_act(float v, int act, float alpha) {

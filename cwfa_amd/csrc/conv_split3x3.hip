@@ -100,7 +100,7 @@ enum { EPI_RUNTIME = -1, EPI_COUPLE = -2 };
 // the soft clamp of the coupling blocks (coupling_layers.py:50-60; same expressions as csrc/elementwise.hip)
 __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
     switch (kind) {
-        case CWFA_CLAMP_ATAN: return clamp * (0.636f * atanf(a));
+        case CWFA_CLAMP_ATAN: return clamp * (0.636f * cwfa_atan(a));
         case CWFA_CLAMP_TANH: return clamp * tanhf(a);
         case CWFA_CLAMP_SIGMOID: return clamp * (2.f * (1.f / (1.f + expf(-a)) - 0.5f));
         default: return clamp * a;
