@@ -35,12 +35,12 @@ class ChainGrads(C.Structure):
 class ConvOpts(C.Structure):
     _fields_ = [("bias", c_f32p), ("act", C.c_int), ("prelu_alpha", c_f32p), ("residual", c_f32p), ("res_bs", C.c_int64),
                 ("act2", C.c_int), ("in_scale", c_f32p), ("in_shift", c_f32p), ("in_affine_bs", C.c_int), ("in_add", c_f32p),
-                ("in_add_bs", C.c_int64), ("upshuffle2", C.c_int)]
+                ("in_add_bs", C.c_int64), ("upshuffle2", C.c_int), ("in_blocked8", C.c_int), ("out_blocked8", C.c_int)]
 
 
 class Couple(C.Structure):
     _fields_ = [("x", c_f32p), ("y", c_f32p), ("x_bs", C.c_int64), ("y_bs", C.c_int64), ("n", C.c_int), ("clamp_kind", C.c_int),
-                ("clamp", C.c_float), ("pre_scale", C.c_float), ("rev", C.c_int), ("logdet", c_f64p)]
+                ("clamp", C.c_float), ("pre_scale", C.c_float), ("rev", C.c_int), ("logdet", c_f64p), ("in_blocked8", C.c_int)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/cwfa_hip.h (tests/test_boundary.py checks)
@@ -106,7 +106,7 @@ SIGNATURES = {
     "cwfa_conv3x3_split_couple_f32": (i, [p, p, p, i, i, i, i, i64, C.POINTER(Couple), p]),
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),
     "cwfa_subnet_layer_split_pack_f32": (i, [p, p, p, p]),
-    "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, p]),
+    "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, i, p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

@@ -316,7 +316,7 @@ __device__ __forceinline__ void stg_off(float* base, unsigned byte_off, float v)
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
 // ------------------------------------------------------------------------------------------------ epilogues
-enum { EPI_GENERIC = 0, EPI_NONE, EPI_ELU, EPI_RES_ELU, EPI_PRELU, EPI_RES_PRELU, EPI_GELU_RES, EPI_UP, EPI_COUNT };
+enum { EPI_GENERIC = 0, EPI_NONE, EPI_ELU, EPI_RES_ELU, EPI_PRELU, EPI_RES_PRELU, EPI_GELU_RES, EPI_UP, EPI_NONE_BLK8, EPI_COUNT };
 
 template <int EPI>
 struct EpiTraits {
@@ -408,6 +408,26 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const Tile& t, f32
                         } else {
                             o[0] = v0; o[1] = v1; o[W2] = v2; o[W2 + 1] = v3;
                         }
+                    }
+                }
+        } else if constexpr (EPI == EPI_NONE_BLK8) {
+            // bias only, output CHANNEL-BLOCKED [Cout/8][H][W][8] (cwfa_conv_opts.out_blocked8): registers 4q .. 4q+3 of a lane
+            // are the channels 8q + 4 kh + {0..3} of its pixel = 16 contiguous bytes of the pixel's entry in block 4 m' + q
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = t.ct * C::CT + (t.wm * C::MT + m) * 32 + 8 * q + 4 * t.kh;       // multiple of 4; Cout % 8 == 0
+                    if (co >= p.Cout) continue;
+                    const f32x4 b4 = p.o.bias ? *reinterpret_cast<const f32x4*>(p.o.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) {
+                        const int row = t.row0 + t.wn * C::NT + n;
+                        if (row >= p.H || col >= p.W) continue;
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = acc[m][n][4 * q + i] + b4[i];
+                        *reinterpret_cast<f32x4*>(yb + ((int64_t)(co >> 3) * HW + (int64_t)row * p.W + col) * 8 + (co & 4)) = v;
                     }
                 }
         } else {
@@ -612,6 +632,7 @@ Sel select_cfg(int ks, int Cout) {
 
 int classify_epilogue(const cwfa_conv_opts& o) {
     const bool res = o.residual != nullptr;
+    if (o.out_blocked8) return EPI_NONE_BLK8;                 // (the entry point checked: bias only)
     if (o.upshuffle2) return (!res && o.act == CWFA_ACT_NONE && o.act2 == CWFA_ACT_NONE) ? EPI_UP : EPI_GENERIC;
     if (!res && o.act2 == CWFA_ACT_NONE) {
         if (o.act == CWFA_ACT_NONE) return EPI_NONE;
@@ -663,7 +684,7 @@ int launch_epi(ConvParams p, hipStream_t stream) {
 // the (config, epilogue, prologue) triples the model uses get a specialised kernel; everything else is generic
 template <class C, unsigned ALLOWED, bool PRO>
 int launch_sel(const ConvParams& p, int epi, hipStream_t st) {
-    if (!(ALLOWED & (1u << epi))) epi = EPI_GENERIC;
+    if (!(ALLOWED & (1u << epi)) && epi != EPI_NONE_BLK8) epi = EPI_GENERIC;
     switch (epi) {
         case EPI_NONE: if constexpr (ALLOWED & (1u << EPI_NONE)) return launch_epi<C, EPI_NONE, PRO>(p, st); break;
         case EPI_ELU: if constexpr (ALLOWED & (1u << EPI_ELU)) return launch_epi<C, EPI_ELU, PRO>(p, st); break;
@@ -672,6 +693,10 @@ int launch_sel(const ConvParams& p, int epi, hipStream_t st) {
         case EPI_RES_PRELU: if constexpr (ALLOWED & (1u << EPI_RES_PRELU)) return launch_epi<C, EPI_RES_PRELU, PRO>(p, st); break;
         case EPI_GELU_RES: if constexpr (ALLOWED & (1u << EPI_GELU_RES)) return launch_epi<C, EPI_GELU_RES, PRO>(p, st); break;
         case EPI_UP: if constexpr (ALLOWED & (1u << EPI_UP)) return launch_epi<C, EPI_UP, PRO>(p, st); break;
+        case EPI_NONE_BLK8:
+            if constexpr (ALLOWED & (1u << EPI_NONE_BLK8)) return launch_epi<C, EPI_NONE_BLK8, PRO>(p, st);
+            cwfa_set_error("cwfa_conv2d_f32: out_blocked8 is built for the 1x1 kernels with 33..64 output channels");
+            return CWFA_E_SHAPE;
         default: break;
     }
     return launch_epi<C, EPI_GENERIC, PRO>(p, st);
@@ -970,6 +995,7 @@ extern "C" int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, 
 
 extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                    int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(!(opts && (opts->in_blocked8 || opts->out_blocked8)), CWFA_E_INVAL, "cwfa_conv_split_f32: blocked layouts are not built here");
     CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv_split_f32: null pointer");
     CWFA_REQUIRE(ks == 1, CWFA_E_SHAPE, "cwfa_conv_split_f32: kernel size %d (1x1 only; 3x3: cwfa_conv3x3_split_f32)", ks);
     SplitParams sp{};
@@ -1045,6 +1071,11 @@ extern "C" int cwfa_conv2d_pack_f32(const float* w, float* packed, int Cout, int
 
 extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(!(opts && opts->in_blocked8), CWFA_E_INVAL, "cwfa_conv2d_f32: in_blocked8 is a cwfa_conv3x3_split_f32 feature");
+    CWFA_REQUIRE(!(opts && opts->out_blocked8) || (ks == 1 && Cout % 8 == 0 && !opts->residual && opts->act == CWFA_ACT_NONE &&
+                                                   opts->act2 == CWFA_ACT_NONE && !opts->upshuffle2 && !opts->in_scale && !opts->in_add &&
+                                                   cwfa_aligned16(y) && (y_bs & 3) == 0 && (!opts->bias || cwfa_aligned16(opts->bias))),
+                 CWFA_E_INVAL, "cwfa_conv2d_f32: out_blocked8 needs a plain 1x1 bank (bias only), Cout %% 8 == 0 and 16-byte aligned y / bias");
     const Sel s = select_cfg(ks, Cout);
     CWFA_REQUIRE(s.id >= 0, CWFA_E_SHAPE, "cwfa_conv2d_f32: kernel size %d not in {1,3,7}", ks);
     ConvParams p{};
@@ -1055,14 +1086,14 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
     hipStream_t st = (hipStream_t)stream;
     if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_conv(x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, p.o, st);
     constexpr unsigned N = 1u << EPI_NONE, E = 1u << EPI_ELU, RE = 1u << EPI_RES_ELU, P = 1u << EPI_PRELU,
-                       RP = 1u << EPI_RES_PRELU, G = 1u << EPI_GELU_RES, U = 1u << EPI_UP;
+                       RP = 1u << EPI_RES_PRELU, G = 1u << EPI_GELU_RES, U = 1u << EPI_UP, K = 1u << EPI_NONE_BLK8;
     // 1x1: rows of 4-pixel groups on 16-byte boundaries (image, skip tensor, batch strides) take the vector-staged kernels
     const bool v4 = ks == 1 && (W & 3) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (!p.o.in_add || ((p.o.in_add_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.o.in_add) & 15) == 0));
     if (v4) {
         switch (s.id) {
             case 3: return launch<C1v_32, N | P | G, P>(p, epi, st);
-            case 4: return launch<C1v_64, N | RE | G, 0>(p, epi, st);
+            case 4: return launch<C1v_64, N | RE | G | K, 0>(p, epi, st);
             default: return launch<C1v_128, N | U, U>(p, epi, st);
         }
     }
@@ -1071,7 +1102,7 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
         case 1: return launch<C3_64, N | E | P | RP, 0>(p, epi, st);
         case 2: return launch<C3_128, N | P, P>(p, epi, st);
         case 3: return launch<C1_32, N | P | G, P>(p, epi, st);
-        case 4: return launch<C1_64, N | RE | G, 0>(p, epi, st);
+        case 4: return launch<C1_64, N | RE | G | K, 0>(p, epi, st);
         case 5: return launch<C1_128, N | U, U>(p, epi, st);
         case 6: return launch<C7_32, N, 0>(p, epi, st);
         default: return launch<C7_64, N, 0>(p, epi, st);

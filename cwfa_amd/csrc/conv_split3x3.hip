@@ -140,7 +140,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         const int r = eidx[k] / XC, c = eidx[k] % XC;
         const int gr = row0 + r - 1, gc = col0 + c - 1;
         fok[k] = fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-        fo[k] = fok[k] ? (unsigned)((gr * p.W + gc) * 4) : OOB;
+        // blocked input ([Cin/8][H][W][8], cwfa_conv_opts.in_blocked8): the 32-byte entry of the pixel; its channel block rides
+        // in the scalar offset
+        fo[k] = !fok[k] ? OOB : p.o.in_blocked8 ? (unsigned)((gr * p.W + gc) * 32) : (unsigned)((gr * p.W + gc) * 4);
     }
     const int xbytes = p.Cin * plane;                   // channels >= Cin: out of range, 0.0
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)b * p.x_bs), 0, xbytes, 0x00020000);
@@ -157,6 +159,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     auto load_entry = [&](auto kc, float (&xv)[8], float (&av)[8], int chunk) {
         constexpr int k = decltype(kc)::value;
         const int ch0 = chunk * 16 + ekh[k] * 8;
+        if (!ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each
+            const f32x4 lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane, 0));
+            const f32x4 hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane + 16, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[j] = lo4[j];
+                xv[4 + j] = hi4[j];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo[k], (ch0 + j) * plane, 0));
         if constexpr (ADD) {
@@ -533,6 +545,9 @@ extern "C" int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packe
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.x_bs = x_bs; p.y_bs = cp->y_bs;
     p.Cout = cwfa_couple_rows(cp->n, nullptr);
     p.o.bias = bias_rows;
+    p.o.in_blocked8 = cp->in_blocked8;
+    CWFA_REQUIRE(!cp->in_blocked8 || (Cin % 8 == 0 && cwfa_aligned16(x) && (x_bs & 3) == 0), CWFA_E_ALIGN,
+                 "cwfa_conv3x3_split_couple_f32: blocked input needs Cin %% 8 == 0 and 16-byte alignment");
     p.cp = *cp;
     p.nchunks = (Cin + 15) / 16;
     p.nsteps = nsteps_of(Cin);
@@ -579,6 +594,8 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
     if (opts) p.o = *opts;
     CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: upshuffle2 is a 1x1 feature");
+    CWFA_REQUIRE(!p.o.in_blocked8 || (Cin % 8 == 0 && cwfa_aligned16(x) && (x_bs & 3) == 0 && !p.o.in_scale && !p.o.in_add), CWFA_E_ALIGN,
+                 "cwfa_conv3x3_split_f32: blocked input needs Cin %% 8 == 0, 16-byte alignment and no load-side affine / add");
     CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "cwfa_conv3x3_split_f32: in_scale without in_shift");
     CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
                  "cwfa_conv3x3_split_f32: bad activation");

@@ -24,6 +24,11 @@
 //                  operand of the 1x1 GEMM, register by register (the k order inside a step is permuted accordingly
 //                  when W1 is packed); its 16 results overwrite the accumulators they came from, and the epilogue
 //                  (+x, ELU, store) of n-tile i is slotted between the MFMAs of n-tile i+1.
+// Layouts.  NCHW planes cost this kernel one dword instruction per (channel, pixel run): 8 loads per staging entry, 64
+// residual loads and 64 stores per thread and tile -- the stores alone held 15 % of the launch.  The maps BETWEEN the layers
+// of a sub-network are private to it, so they may be kept channel-blocked, [C/8][H][W][8]: a staging entry (8 channels of a
+// pixel) is 32 contiguous bytes (two 16-byte loads), and the four channels 16 mt + 4 g + r a lane holds for a pixel are 16
+// contiguous bytes (one 16-byte residual load and one 16-byte store per accumulator tile).
 // Weights: 20 slices of 12 KB ([piece][k group 4][64 cout][8]) stream through a three-slot LDS ring by LDS-DMA; slice
 // s+2 is issued at the start of step s and verified at its end (one barrier per step, 19 per tile).
 #include "conv_internal.h"
@@ -58,6 +63,7 @@ struct LParams {
     const float* b1;
     int B, H, W, tiles_x, tiles_y, ntiles;
     int64_t x_bs, y_bs;
+    int in_blocked, out_blocked;      // layout of x / y: 0 = NCHW planes, 1 = [C/8][H][W][8] (see the header comment)
 };
 
 template <int K>
@@ -99,7 +105,7 @@ __host__ __device__ constexpr int unit_off(int u) {
     return (chunk & 1) * XB + ((tap / 3) * XC + tap % 3) * 16;
 }
 
-template <bool SIX>
+template <bool SIX, bool INB, bool OUTB>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
@@ -110,23 +116,25 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     // ---- staging entries e = tid + k*512 < NE of the [k half][18 rows][34 px] tile
-    int er[3], ec[3], eh[3];
+    // (kept as ONE packed word + the LDS destination per entry: the kernel sits at the 256-register limit)
+    int epk[3], edst[3];                       // column | row << 8 | k half << 16;  byte offset of the entry in an input buffer
     bool fin[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int e = tid + k * 512;
         fin[k] = e < NE;
-        ec[k] = e % XC;
-        er[k] = (e / XC) % XR;
-        eh[k] = (e / (XR * XC)) & 1;
+        const int c_ = e % XC, r_ = (e / XC) % XR, h_ = (e / (XR * XC)) & 1;
+        epk[k] = c_ | (r_ << 8) | (h_ << 16);
+        edst[k] = h_ * KHB + (r_ * XC + c_) * 16;
     }
     const bool stage2 = wave < 4;              // entry 2 exists only for tid < 200: waves 0..3 (wave 3 partly)
     auto entry_offsets = [&](bool valid, int row0, int col0, unsigned (&fo)[3]) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int gr = row0 + er[k] - 1, gc = col0 + ec[k] - 1;
+            const int gr = row0 + ((epk[k] >> 8) & 255) - 1, gc = col0 + (epk[k] & 255) - 1, eh = epk[k] >> 16;
             const bool ok = valid && fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
-            fo[k] = ok ? (unsigned)((eh[k] * 8 * HW + gr * p.W + gc) * 4) : OOB;
+            // NCHW: channel 8 eh of the chunk, pixel (gr, gc); blocked: 32-byte entry (gr, gc) of channel block eh of the chunk
+            fo[k] = !ok ? OOB : INB ? (unsigned)((eh * HW + gr * p.W + gc) * 32) : (unsigned)((eh * 8 * HW + gr * p.W + gc) * 4);
         }
     };
     auto rsrc_of = [&](const float* base) {
@@ -140,24 +148,29 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         row0 = ty * TR;
         col0 = (rem - ty * p.tiles_x) * TC;
     };
-    auto load_entry = [&](float (&xv)[8], const float* base, unsigned fo, int chunk) {
+    auto load_entry = [&](f32x4 (&xv)[2], const float* base, unsigned fo, int chunk) {
         const auto rs = rsrc_of(base);
+        if constexpr (INB) {                          // chunk = channel blocks 2 chunk, 2 chunk + 1: 16 planes further
+            xv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, fo, chunk * 16 * plane, 0));
+            xv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, fo, chunk * 16 * plane + 16, 0));   // (+16 in the SCALAR offset)
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, fo, (chunk * 16 + j) * plane, 0));
+            xv[j >> 2][j & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, fo, (chunk * 16 + j) * plane, 0));
     };
-    auto store_entry = [&](auto kc, const float (&xv)[8], int buf) {
+    auto store_entry = [&](auto kc, const f32x4 (&xv)[2], int buf) {
         constexpr int k = decltype(kc)::value;
         if (k == 2 && !stage2) return;
         bf16x8 pc[3];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __bf16 a1, a2 = (__bf16)0.f, a3 = (__bf16)0.f;
-            split3<SIX>(xv[j], a1, a2, a3);
+            split3<SIX>(xv[j >> 2][j & 3], a1, a2, a3);
             pc[0][j] = a1; pc[1][j] = a2; pc[2][j] = a3;
         }
         if (fin[k]) {
-            char* dst = lds + buf * XB + eh[k] * KHB + (er[k] * XC + ec[k]) * 16;
+            char* dst = lds + buf * XB + edst[k];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
         }
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
 
     f32x4 acc[4][4];
     bf16x8 A[2][3], Bq[4][3];
-    float xa[3][8], xb[3][8];                   // staged entries of the next even / odd chunk
+    f32x4 xa[3][2], xb[3][2];                   // staged entries (8 channels of a pixel) of the next even / odd chunk
     unsigned fo_c[3], fo_n[3];                  // entry offsets in the current / next tile
 
     auto read_a = [&](int set, int abase, int mt) {
@@ -297,7 +310,9 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             // this step's slice DMA has landed; its 8 staging loads (issued after it) may stay in flight
             // (LDS: everything but the 12 youngest operations -- the B fragments just requested for the next step -- is done:
             //  this step's staging stores, and every read of the weight slot and input buffer that get overwritten next)
-            if constexpr (LOADS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // (8 four-byte loads per entry from NCHW planes, two 16-byte loads from a channel-blocked map)
+            if constexpr (LOADS && !INB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LOADS) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (S != 17 && SIX) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -311,37 +326,68 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             dma_w(0, sn0);
             const auto rx = rsrc_of(p.x + (int64_t)tb * p.x_bs);
             const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)tb * p.y_bs, 0, 64 * plane, 0x00020000);
-            unsigned oo[4];
+            // offsets of this lane's (row, col) in the two layouts: NCHW: channel 4 g (+ 16 mt + r planes in the scalar offset);
+            // blocked: 16-byte half g & 1 of the 32-byte entry of channel block g >> 1 (+ 2 mt blocks = 16 mt planes)
+            unsigned oo[4], ob[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int row = row0 + 2 * wave + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
-                oo[nt] = (col < p.W && row < p.H) ? (unsigned)(row * p.W + col) * 4u + (unsigned)g * 4u * (unsigned)plane : OOB;
+                const bool ok = col < p.W && row < p.H;
+                if constexpr (!INB || !OUTB) oo[nt] = ok ? (unsigned)(row * p.W + col) * 4u + (unsigned)g * 4u * (unsigned)plane : OOB;
+                if constexpr (INB || OUTB) ob[nt] = ok ? (unsigned)((g >> 1) * HW + row * p.W + col) * 32u + (unsigned)(g & 1) * 16u : OOB;
             }
-            f32x4 res[2][4];
+            f32x4 res[4];                           // residual of ONE n-tile: loaded at the end of the iteration before its epilogue
             auto load_res = [&](int nt, f32x4 (&rv)[4]) {
+                if constexpr (INB) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        rv[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ob[nt], mt * 16 * plane, 0));
+                    return;
+                }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         rv[mt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, oo[nt], (mt * 16 + r) * plane, 0));
             };
-            // +x, ELU, store of two of the 16 results of n-tile nt (piece i = 0..7)
+            // +x, ELU, store of two of the 16 results of n-tile nt (piece i = 0..7); blocked output: the four results of an
+            // accumulator tile leave as ONE 16-byte store with its second piece
             auto epilogue_piece = [&](int nt, int i, const f32x4 (&rv)[4]) {
+                const int mt = i >> 1;
+                if constexpr (OUTB) {
+                    if (i & 1) {
+                        f32x4 o4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o4[r] = elu(acc[mt][nt][r] + rv[mt][r]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o4), ry, ob[nt],
+                                                               mt * 16 * plane, 0);
+                        // gfx950: the data registers of a 16-byte buffer store are still being read in the cycles after its issue --
+                        // also when its offset field is an SGPR, the case the compiler's hazard rule exempts (observed: a
+                        // v_pk_add_f32 into the tuple directly behind the store corrupted its second dword in the last lanes
+                        // of every row group).  Two wait states, pinned behind the store.
+                        asm volatile("s_nop 1");
+                        FENCE();
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int mt = i >> 1, r = (i & 1) * 2 + h;
+                    const int r = (i & 1) * 2 + h;
                     const float v = elu(acc[mt][nt][r] + rv[mt][r]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, oo[nt], (mt * 16 + r) * plane, 0);
                 }
             };
             const int a0 = alane + sw0 * WSL, a1 = alane + sw1 * WSL;
-            bf16x8 A1[2][2][3];                     // two sets of W1 fragments: sub-block i = (m-tile pair i >> 1, k step i & 1)
+            // W1 fragments of sub-block i = (m-tile pair i >> 1, k step i & 1): two sets (the next one is read while this one
+            // multiplies)
+            constexpr int NA1 = 2;
+            bf16x8 A1[NA1][2][3];
             auto read_a1 = [&](int i) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
-                        A1[i & 1][h][q] = *reinterpret_cast<const bf16x8*>(lds + ((i & 1) ? a1 : a0) + (q * 256 + ((i >> 1) * 2 + h) * 16) * 16);
+                        A1[i & (NA1 - 1)][h][q] = *reinterpret_cast<const bf16x8*>(lds + ((i & 1) ? a1 : a0) + (q * 256 + ((i >> 1) * 2 + h) * 16) * 16);
             };
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -356,30 +402,32 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                         split3<SIX>(elu(acc[2 * s + (j >> 2)][nt][j & 3]), h1, h2, h3);
                         Hq[s][0][j] = h1; Hq[s][1][j] = h2; Hq[s][2][j] = h3;
                     }
-                load_res(nt, res[nt & 1]);          // consumed by this n-tile's epilogue, one iteration later
                 read_a1(0);
                 FENCE();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {       // (m-tile pair, k step): 12 MFMAs on two accumulator tiles
                     const int mp = (i >> 1) * 2, s = i & 1;
-                    if (i + 1 < 4) read_a1(i + 1);
+                    if (NA1 == 2 && i + 1 < 4) read_a1(i + 1);
+                    if (NA1 == 1 && i > 0) read_a1(i);
                     if (s == 0) {
                         acc[mp][nt] = bias4[16 + mp * 4 + g];
                         acc[mp + 1][nt] = bias4[16 + (mp + 1) * 4 + g];
                     }
                     FENCE();
-                    mfma6(acc[mp][nt], A1[i & 1][0], Hq[s]);
-                    mfma6(acc[mp + 1][nt], A1[i & 1][1], Hq[s]);
+                    mfma6(acc[mp][nt], A1[i & (NA1 - 1)][0], Hq[s]);
+                    mfma6(acc[mp + 1][nt], A1[i & (NA1 - 1)][1], Hq[s]);
                     FENCE();
                     if (nt > 0) {
-                        epilogue_piece(nt - 1, 2 * i, res[(nt - 1) & 1]);
-                        epilogue_piece(nt - 1, 2 * i + 1, res[(nt - 1) & 1]);
+                        epilogue_piece(nt - 1, 2 * i, res);
+                        epilogue_piece(nt - 1, 2 * i + 1, res);
                         FENCE();
                     }
                 }
+                load_res(nt, res);                  // consumed by this n-tile's epilogue, one iteration later
+                FENCE();
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) epilogue_piece(3, i, res[1]);
+            for (int i = 0; i < 8; ++i) epilogue_piece(3, i, res);
             // slice 0 of the next tile (issued at the start of this phase) has landed; the 16 youngest stores may stay in flight
             asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -453,7 +501,12 @@ extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1
 }
 
 extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
-                                           int H, int W, int64_t x_bs, int64_t y_bs, void* stream) {
+                                           int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream) {
+    CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);
+    CWFA_REQUIRE(!(layout & 1) || cwfa_aligned16(x), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input must be 16-byte aligned");
+    CWFA_REQUIRE(!(layout & 2) || cwfa_aligned16(y), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output must be 16-byte aligned");
+    CWFA_REQUIRE(!(layout & 1) || (x_bs & 3) == 0, CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input batch stride must be a multiple of 4");
+    CWFA_REQUIRE(!(layout & 2) || (y_bs & 3) == 0, CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output batch stride must be a multiple of 4");
     CWFA_REQUIRE(B >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: bad size");
     if (B == 0 || H == 0 || W == 0) return CWFA_OK;
     CWFA_REQUIRE(x && packed && b3 && b1 && y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: null pointer");
@@ -463,6 +516,8 @@ extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, c
     LParams p{};
     p.x = x; p.y = y; p.wp = packed; p.b3 = b3; p.b1 = b1;
     p.B = B; p.H = H; p.W = W; p.x_bs = x_bs; p.y_bs = y_bs;
+    p.in_blocked = layout & 1;
+    p.out_blocked = (layout >> 1) & 1;
     p.tiles_x = (W + TC - 1) / TC;
     p.tiles_y = (H + TR - 1) / TR;
     const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * B;
@@ -477,15 +532,22 @@ extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, c
         g_num_cus = n;
     }
     const bool six = g_cwfa_split_products != 1;
-    auto kern = six ? &split_layer_kernel<true> : &split_layer_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[six]) {
+    typedef void (*kern_t)(LParams);
+    static const kern_t kerns[2][4] = {
+        {&split_layer_kernel<false, false, false>, &split_layer_kernel<false, true, false>, &split_layer_kernel<false, false, true>,
+         &split_layer_kernel<false, true, true>},
+        {&split_layer_kernel<true, false, false>, &split_layer_kernel<true, true, false>, &split_layer_kernel<true, false, true>,
+         &split_layer_kernel<true, true, true>}};
+    kern_t kern = kerns[six][layout];
+    static bool attr_set_all[2][4] = {};
+    bool& attr_done = attr_set_all[six][layout];
+    if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             cwfa_set_error("cwfa_subnet_layer_split_f32: hipFuncSetAttribute(%d bytes LDS): %s", LDS_BYTES, hipGetErrorString(e));
             return CWFA_E_HIP;
         }
-        attr_set[six] = true;
+        attr_done = true;
     }
     const int grid = (int)(ntiles < g_num_cus ? ntiles : g_num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, p);

@@ -132,21 +132,34 @@ class wavelet_flow_subnetwork(nn.Module):
         if self.conv_type is not nn.Conv2d:
             raise NotImplementedError("3-D sub-networks are not used by CWFA (every graph uses the 2-D subclasses)")
         P = self._packed.get
-        b = ops.conv2d(u, P(conv_in), bias=conv_in.bias)
         fused = self.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None
                                         for blk in (self.block2, self.block4, self.block6))
-        for blk in (self.block2, self.block4, self.block6):
+        H_, W_ = u.shape[2], u.shape[3]
+        split_layers = fused and ops._split_bf16 >= 2 and 64 * H_ * W_ * 4 < 2 ** 31
+        pc_in = P(conv_in)
+        # the first map is channel-blocked already when the 1x1 kernel that writes it can do so (see below)
+        blocked = bool(split_layers and ops.BLOCKED_MAPS and not pc_in.split and pc_in.ks == 1 and pc_in.cout == 64)
+        b = ops.conv2d(u, pc_in, bias=conv_in.bias, out_blocked=blocked)
+        # the maps between the layers are private to this stack: on the split-bf16 kernels they are kept CHANNEL-BLOCKED
+        # ([8][H][W][8]: 16-byte accesses in the layer kernel, see cwfa_subnet_layer_split_f32) whenever their consumer reads
+        # that layout -- the next layer, and the last convolution if it runs on the split-bf16 3x3 kernel
+        pc_out = None if couple is not None else P(conv_out)
+        last_reads_blocked = split_layers and ops.BLOCKED_MAPS and (couple is not None or (pc_out.split and pc_out.ks == 3))
+        for i, blk in enumerate((self.block2, self.block4, self.block6)):
             if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
-                if ops._split_bf16 >= 2 and 64 * b.shape[2] * b.shape[3] * 4 < 2 ** 31:   # both convs on the bf16 matrix pipe
-                    b = ops.subnet_layer(b, self._split3(blk[0], blk[2]), blk[0].bias, None, blk[2].bias)
+                if split_layers:                                        # both convs on the bf16 matrix pipe
+                    out_blocked = ops.BLOCKED_MAPS and (i < 2 or last_reads_blocked)
+                    b = ops.subnet_layer(b, self._split3(blk[0], blk[2]), blk[0].bias, None, blk[2].bias,
+                                         layout=int(blocked) | (int(out_blocked) << 1))
+                    blocked = out_blocked
                 else:
                     b = ops.subnet_layer(b, P(blk[0]), blk[0].bias, self._panel(blk[2]), blk[2].bias)
                 continue
             h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")
             b = ops.conv2d(h, P(blk[2]), bias=blk[2].bias, residual=b, act2="elu")   # ELU = block3 / block5 / block7x[0]
         if couple is not None:
-            return ops.conv3x3_couple(b, self._couple_bank(conv_out), *couple)
-        return ops.conv2d(b, P(conv_out), bias=conv_out.bias, out=out)
+            return ops.conv3x3_couple(b, self._couple_bank(conv_out), *couple, in_blocked=blocked)
+        return ops.conv2d(b, pc_out, bias=conv_out.bias, out=out, in_blocked=blocked)
 
     def _couple_bank(self, conv):
         w, bias = conv.weight, conv.bias

@@ -370,7 +370,7 @@ def pack_conv_weight(w, transposed=False):
 
 
 def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=None, in_scale=None, in_shift=None,
-           in_add=None, out=None):
+           in_add=None, out=None, in_blocked=False, out_blocked=False):
     """y = act2(act(conv(x') + bias) + residual), x' = x*in_scale[c] + in_shift[c] + in_add.  Transposed banks
     (ConvTranspose2d k2 s2) write the pixel-shuffled [B,Co,2H,2W] output."""
     L = _lib.lib()
@@ -416,6 +416,14 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         o.in_add, o.in_add_bs = in_add.data_ptr(), abs_
         keep.append(in_add)
     o.upshuffle2 = int(up)
+    if in_blocked:                          # x is a channel-blocked map of the fused layer kernel (subnet_layer, layout bit 1)
+        if not (pc.split and pc.ks == 3):
+            raise ValueError("conv2d: channel-blocked input is read by the split-bf16 3x3 kernel only")
+        o.in_blocked8 = 1
+    if out_blocked:                         # y leaves channel-blocked (plain 1x1 banks with 33..64 outputs on the fp32 MFMA kernel)
+        if pc.split or pc.ks != 1 or not (33 <= pc.cout <= 64) or pc.cout % 8 or up:
+            raise ValueError("conv2d: channel-blocked output is written by the direct 1x1 kernel with 40..64 output channels only")
+        o.out_blocked8 = 1
     rec = conv_event_sink
     if rec is not None:                    # bench.py: HIP events around selected launches, on the launch stream
         # the last field names the kernel instantiation the C side dispatches to (prologue / epilogue variant)
@@ -474,7 +482,7 @@ def pack_couple_weight(w, bias):
     return pc, br
 
 
-def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet=None):
+def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet=None, in_blocked=False):
     """out = coupling(x | s, t) with [s_raw | t] = conv3x3(u) + bias taken from the accumulators of the convolution (they never
     reach memory).  ``x`` / ``out``: the active half [B,n,H,W] (channel-slice views allowed; ``out`` may be ``x``)."""
     L = _lib.lib()
@@ -493,6 +501,7 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
     cp.clamp_kind, cp.clamp, cp.pre_scale, cp.rev = _lib.CLAMP[clamp_kind], float(clamp), float(pre_scale), int(bool(rev))
     if logdet is not None:
         cp.logdet = logdet.data_ptr()
+    cp.in_blocked8 = int(bool(in_blocked))
     rec = conv_event_sink
     if rec is not None:
         key = (3, Cin, pc.cout, H, W, B, "||||couple+split", False)
@@ -507,6 +516,7 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
     return out
 
 
+BLOCKED_MAPS = True          # (tuning / ablation) False: the maps between the split-bf16 sub-network layers stay NCHW
 COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
 
 
@@ -544,10 +554,12 @@ def pack_split_layer_weight(w3, w1):
     return pc
 
 
-def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False):
+def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False, layout=0):
     """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch.  ``want_hidden`` (training forward):
     returns (y, h) with h = ELU(conv3x3(x) + b3), written by the same launch.  With ``pc3`` from
-    pack_split_layer_weight (both banks in one split-bf16 image) ``panel1`` is unused."""
+    pack_split_layer_weight (both banks in one split-bf16 image) ``panel1`` is unused; ``layout`` (split image only): bit 0 /
+    bit 1 = input / output tensor is channel-blocked [B][8][H][W][8] (cwfa_subnet_layer_split_f32) -- the tensor object keeps
+    the shape [B,64,H,W], only its memory order differs; the consumer must be told (layout bit 0, or ``in_blocked``)."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
@@ -567,9 +579,11 @@ def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False):
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+    if layout and not pc3.split:
+        raise ValueError("subnet_layer: channel-blocked maps exist on the split-bf16 layer kernel only")
     if pc3.split:
         check(L.cwfa_subnet_layer_split_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), B, H, W,
-                                            xbs, 64 * H * W, _stream()), "subnet_layer_split")
+                                            xbs, 64 * H * W, int(layout), _stream()), "subnet_layer_split")
     else:
         check(L.cwfa_subnet_layer_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), B, H, W,
                                       xbs, 64 * H * W, _stream()), "subnet_layer")

@@ -195,6 +195,11 @@ typedef struct {
     int upshuffle2;           /* 1: the Cout = 4*Co outputs are written pixel-shuffled to [B,Co,2H,2W]
                                  (ConvTranspose2d k=2 s=2 as a 1x1 conv, unet.py:166); residual/bias then
                                  index the shuffled output ([Co])                                         */
+    int in_blocked8;          /* cwfa_conv3x3_split_f32 only: x is channel-blocked [B][Cin/8][H][W][8] (what
+                                 cwfa_subnet_layer_split_f32 writes with layout bit 1); Cin % 8 == 0, no in_* */
+    int out_blocked8;         /* cwfa_conv2d_f32, 1x1 banks with 33..64 outputs, bias only: y is written
+                                 channel-blocked [B][Cout/8][H][W][8] (the first convolution of a coupling
+                                 sub-network feeding cwfa_subnet_layer_split_f32 with layout bit 0)          */
 } cwfa_conv_opts;
 
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
@@ -301,6 +306,7 @@ typedef struct {
     float clamp, pre_scale;
     int rev;
     double* logdet;
+    int in_blocked8;            /* the convolution's input is channel-blocked (see cwfa_conv_opts.in_blocked8)           */
 } cwfa_couple;
 int cwfa_couple_rows(int n, int* rows);
 int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packed, const float* bias_rows, int B, int Cin, int H, int W,
@@ -314,7 +320,12 @@ int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packed, const fl
 int64_t cwfa_subnet_layer_split_packed_bytes(void);
 int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream);
 int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H,
-                                int W, int64_t x_bs, int64_t y_bs, void* stream);
+                                int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
+/* layout: bit 0 = x, bit 1 = y is CHANNEL-BLOCKED, [B][8 blocks][H][W][8 channels] (same size and batch strides as NCHW, 16-byte
+ * aligned), instead of NCHW planes.  The maps between the layers of one sub-network are private to it; blocked, a staging entry
+ * of the kernel (8 channels of a pixel) is two 16-byte loads instead of eight 4-byte ones and the four channels a lane holds for
+ * a pixel leave as one 16-byte store (the 4-byte stores of the NCHW form held 15 % of a launch).  The consumer of a blocked map:
+ * this function with bit 0, or cwfa_conv3x3_split_f32 / cwfa_conv3x3_split_couple_f32 with `in_blocked8`. */
 
 /* ------------------------------------------------------------------------------------------------
  * Lenslet views (the step before the path): XLFMDatasetFull.extract_views XLFMDataset.py:212-242 followed by the

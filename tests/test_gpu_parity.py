@@ -1171,6 +1171,61 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
         assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")
 
 
+def _to_blocked(t):
+    B, Cc, H, W = t.shape
+    return t.view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, Cc, H, W)
+
+
+def _from_blocked(t):
+    B, Cc, H, W = t.shape
+    return t.view(B, Cc // 8, H, W, 8).permute(0, 1, 4, 2, 3).contiguous().view(B, Cc, H, W)
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 50, 70), (1, 33, 64), (1, 128, 96), (1, 20, 41)])
+def test_split_layer_channel_blocked_layouts(shape):
+    """cwfa_subnet_layer_split_f32 with channel-blocked input / output ([8][H][W][8]): the same arithmetic, only the memory
+    order of the maps differs -> bit-identical to the NCHW form in all four combinations; and the split 3x3 convolution
+    (plain and with the coupling epilogue) reading a blocked map."""
+    from cwfa_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, 64, H, W, generator=g).cuda()
+    w3, b3 = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    w1, b1 = (torch.randn(64, 64, 1, 1, generator=g) / 8).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    ops.set_precision("split_bf16")
+    try:
+        pc = ops.pack_split_layer_weight(w3, w1)
+        y0 = ops.subnet_layer(x, pc, b3, None, b1)
+        xb = _to_blocked(x)
+        assert torch.equal(_from_blocked(xb), x)
+        assert torch.equal(_from_blocked(ops.subnet_layer(x, pc, b3, None, b1, layout=2)), y0)
+        assert torch.equal(ops.subnet_layer(xb, pc, b3, None, b1, layout=1), y0)
+        assert torch.equal(_from_blocked(ops.subnet_layer(xb, pc, b3, None, b1, layout=3)), y0)
+        for cout in (96, 48):
+            wl, bl = (torch.randn(cout, 64, 3, 3, generator=g) / 24).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+            pl = ops.pack_conv_weight(wl)
+            assert pl.split
+            assert torch.equal(ops.conv2d(xb, pl, bias=bl, in_blocked=True), ops.conv2d(x, pl, bias=bl))
+        n = 24
+        wl, bl = (torch.randn(2 * n, 64, 3, 3, generator=g) / 24).cuda(), (torch.randn(2 * n, generator=g) * 0.1).cuda()
+        bank = ops.pack_couple_weight(wl, bl)
+        xa = torch.randn(B, n, H, W, generator=g).cuda()
+        o0, o1 = torch.empty_like(xa), torch.empty_like(xa)
+        ops.conv3x3_couple(x, bank, xa, o0, "ATAN", 2.0, 1.0, True)
+        ops.conv3x3_couple(xb, bank, xa, o1, "ATAN", 2.0, 1.0, True, in_blocked=True)
+        assert torch.equal(o0, o1)
+        with pytest.raises(ValueError):
+            ops.conv2d(xb, ops.pack_1x1_panel(w1), in_blocked=True)
+        # the producer of the first map: the direct 1x1 kernel writing channel-blocked (both staging forms: W % 4 == 0 or not)
+        for cin in (48, 6):
+            wi, bi = (torch.randn(64, cin, 1, 1, generator=g) / cin ** 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+            pi = ops.pack_conv_weight(wi)
+            ui = torch.randn(B, cin, H, W, generator=g).cuda()
+            assert torch.equal(_from_blocked(ops.conv2d(ui, pi, bias=bi, out_blocked=True)), ops.conv2d(ui, pi, bias=bi))
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""

@@ -44,7 +44,7 @@ def run_one(name):
         ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
         y = ops.subnet_layer(x.cuda(), ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda()).cpu().double()
         res["err_" + tag] = float((y - ref).abs().max() / ref.abs().max())
-    for B in (1, 4):
+    for B in (1, 4, 10):
         x = torch.randn(B, 64, 512, 512, device="cuda")
         w3, b3 = torch.randn(64, 64, 3, 3, device="cuda") / 24, torch.randn(64, device="cuda") * 0.1
         w1, b1 = torch.randn(64, 64, 1, 1, device="cuda") / 8, torch.randn(64, device="cuda") * 0.1
@@ -53,7 +53,9 @@ def run_one(name):
         ya = ops.subnet_layer(x, pa, b3, pn, b1)
         yb = ops.subnet_layer(x, pb, b3, None, b1)
         res[f"vs_fp32_layer_B{B}"] = float((ya - yb).abs().max() / ya.abs().max())
-        for mode, f in (("split", lambda: ops.subnet_layer(x, pb, b3, None, b1)), ("fp32", lambda: ops.subnet_layer(x, pa, b3, pn, b1))):
+        for mode, f in (("split", lambda: ops.subnet_layer(x, pb, b3, None, b1)), ("fp32", lambda: ops.subnet_layer(x, pa, b3, pn, b1)),
+                        ("split_l1", lambda: ops.subnet_layer(x, pb, b3, None, b1, layout=1)), ("split_l2", lambda: ops.subnet_layer(x, pb, b3, None, b1, layout=2)),
+                        ("split_l3", lambda: ops.subnet_layer(x, pb, b3, None, b1, layout=3))):
             for _ in range(3): f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -79,7 +81,7 @@ def run_one(name):
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build({a.split("=")[0]: [d for d in a.split("=")[1].split(",") if d] for a in sys.argv[2:]})
+        build({a.split("=", 1)[0]: [d for d in a.split("=", 1)[1].split(",") if d] for a in sys.argv[2:]})
     elif sys.argv[1] == "run":
         for name in (sys.argv[2:] or ["default"]):
             subprocess.run([sys.executable, __file__, "one", name])
