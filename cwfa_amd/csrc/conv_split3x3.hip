@@ -159,7 +159,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     auto load_entry = [&](auto kc, float (&xv)[8], float (&av)[8], int chunk) {
         constexpr int k = decltype(kc)::value;
         const int ch0 = chunk * 16 + ekh[k] * 8;
-        if (!ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each
+        if (!ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each (the
+                                                        // load-side affine is per channel: unchanged)
             const f32x4 lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane, 0));
             const f32x4 hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane + 16, 0));
 #pragma unroll
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         }
         return;
     }
+    const bool outb = p.o.out_blocked8 != 0;           // (uniform) y channel-blocked [Cout/8][H][W][8]: the lane's four channels = 16 bytes
 #pragma unroll
     for (int mt = 0; mt < MPW; ++mt) {
         float bias[4];
@@ -420,6 +422,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int row = row0 + wn * 4 + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            if constexpr (ACT1 != EPI_RUNTIME) {
+                if (outb) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = act_of<ACT1>(acc[mt][nt][r] + bias[r], alpha);
+                    const unsigned pb = (row < p.H && col < p.W) ? (unsigned)(((g >> 1) * HW + row * p.W + col) * 32 + (g & 1) * 16) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o4), ry, pb,
+                                                           (cwave + mt * 16) * plane, 0);
+                    asm volatile("s_nop 1");          // store-data hazard of 16-byte buffer stores with an SGPR offset (conv_split_layer.hip)
+                    FENCE();
+                    continue;
+                }
+            }
             const unsigned po = (row < p.H && col < p.W) ? (unsigned)((row * p.W + col) * 4) + glane : OOB;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -594,8 +609,11 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
     if (opts) p.o = *opts;
     CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: upshuffle2 is a 1x1 feature");
-    CWFA_REQUIRE(!p.o.in_blocked8 || (Cin % 8 == 0 && cwfa_aligned16(x) && (x_bs & 3) == 0 && !p.o.in_scale && !p.o.in_add), CWFA_E_ALIGN,
-                 "cwfa_conv3x3_split_f32: blocked input needs Cin %% 8 == 0, 16-byte alignment and no load-side affine / add");
+    CWFA_REQUIRE(!p.o.in_blocked8 || (Cin % 8 == 0 && cwfa_aligned16(x) && (x_bs & 3) == 0 && !p.o.in_add), CWFA_E_ALIGN,
+                 "cwfa_conv3x3_split_f32: blocked input needs Cin %% 8 == 0, 16-byte alignment and no added tensor");
+    CWFA_REQUIRE(!p.o.out_blocked8 || (Cout % 8 == 0 && cwfa_aligned16(y) && (y_bs & 3) == 0 && !p.o.residual && p.o.act2 == CWFA_ACT_NONE &&
+                                       (p.o.act == CWFA_ACT_NONE || p.o.act == CWFA_ACT_PRELU)),
+                 CWFA_E_ALIGN, "cwfa_conv3x3_split_f32: blocked output needs Cout %% 8 == 0, 16-byte alignment and a bias / PReLU epilogue");
     CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "cwfa_conv3x3_split_f32: in_scale without in_shift");
     CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
                  "cwfa_conv3x3_split_f32: bad activation");

@@ -420,9 +420,12 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         if not (pc.split and pc.ks == 3):
             raise ValueError("conv2d: channel-blocked input is read by the split-bf16 3x3 kernel only")
         o.in_blocked8 = 1
-    if out_blocked:                         # y leaves channel-blocked (plain 1x1 banks with 33..64 outputs on the fp32 MFMA kernel)
-        if pc.split or pc.ks != 1 or not (33 <= pc.cout <= 64) or pc.cout % 8 or up:
-            raise ValueError("conv2d: channel-blocked output is written by the direct 1x1 kernel with 40..64 output channels only")
+    if out_blocked:                         # y leaves channel-blocked: the split-bf16 3x3 kernel (bias / PReLU epilogue), or plain 1x1
+        ok3 = pc.split and pc.ks == 3 and pc.cout % 8 == 0 and residual is None and act2 is None and act in (None, "prelu")
+        ok1 = not pc.split and pc.ks == 1 and 33 <= pc.cout <= 64 and pc.cout % 8 == 0 and not up
+        if not (ok3 or ok1):                # banks with 33..64 outputs on the fp32 MFMA kernel
+            raise ValueError("conv2d: channel-blocked output is written by the split-bf16 3x3 kernel (bias / PReLU) and by the "
+                             "direct 1x1 kernel with 40..64 output channels only")
         o.out_blocked8 = 1
     rec = conv_event_sink
     if rec is not None:                    # bench.py: HIP events around selected launches, on the launch stream
@@ -517,6 +520,7 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
 
 
 BLOCKED_MAPS = True          # (tuning / ablation) False: the maps between the split-bf16 sub-network layers stay NCHW
+BLOCKED_UNET = False         # the same for the map between the two convolutions of a UNetConvBlock: built and tested, no gain (unet.py)
 COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
 
 
@@ -811,13 +815,16 @@ def conv3d_1k1(x, w1, b1, alpha, w2, b2):
 
 
 # ------------------------------------------------------------------------------------------------ LRNN helpers
-def channel_stats(x):
-    """double[2*C]: per-channel (sum, sumsq) over (B,H,W)."""
+def channel_stats(x, blocked=False):
+    """double[2*C]: per-channel (sum, sumsq) over (B,H,W).  ``blocked``: x is a channel-blocked map ([C/8][H][W][8])."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
     st = torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
-    check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
+    if blocked:
+        check(L.cwfa_channel_stats_blocked8_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats_blocked8")
+    else:
+        check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
     return st
 
 

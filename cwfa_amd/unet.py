@@ -40,11 +40,11 @@ class _Packed:
         return pc
 
 
-def _bn_affine(bn, y, mask_bc=None):
-    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output)."""
+def _bn_affine(bn, y, mask_bc=None, blocked=False):
+    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output; ``blocked``: channel-blocked map)."""
     C = bn.num_features
     if bn.training or not bn.track_running_stats:
-        st = ops.channel_stats(y)
+        st = ops.channel_stats(y, blocked=blocked)
         n = y.numel() // C
         if bn.track_running_stats and bn.momentum is not None:       # buffer bookkeeping, as nn.BatchNorm2d does
             ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
@@ -103,10 +103,16 @@ class UNetConvBlock(nn.Module):
         must apply on load (None when the block has no BatchNorm and no mask)."""
         aff = in_affine
         layers = self._layers()
+        packs = [self._packed.get(conv) for conv, _, _ in layers]
+        blocked = False               # layout of x: the map BETWEEN the two convolutions is private to this block and CAN be kept
+        #                               channel-blocked ([C/8][H][W][8]) on the split-bf16 3x3 kernel (ops.BLOCKED_UNET; off:
+        #                               measured -4 % .. +1 % per convolution and a slower statistics pass, no gain per volume)
         for li, (conv, act, bn) in enumerate(layers):
             kind, alpha = self._act(act)
             sc, sh = aff if aff is not None else (None, None)
             add = in_add if li == 0 else None
+            out_blocked = (ops.BLOCKED_UNET and li == 0 and len(layers) == 2 and kind in (None, "prelu") and
+                           all(pc.split and pc.ks == 3 for pc in packs) and packs[0].cout % 8 == 0)
             if (_MATERIALIZE and ops._split_bf16 < 2 and (sc is not None or add is not None)
                     and (x.shape[2] * x.shape[3]) % 4 == 0):         # (the split / bf16 kernels apply the prologue for free)
                 # one streaming pass writes the BatchNorm (x mask, + skip) output, and the convolution runs without its
@@ -114,12 +120,13 @@ class UNetConvBlock(nn.Module):
                 # kernel (x1.2 on the 512 / 1024-channel layers) only pays off without it -- the pass costs 2-7 %
                 x = ops.plane_affine(x, sc, sh, add=add)
                 sc = sh = add = None
-            x = ops.conv2d(x, self._packed.get(conv), bias=conv.bias, act=kind, prelu_alpha=alpha, in_scale=sc,
-                           in_shift=sh, in_add=add)
+            x = ops.conv2d(x, packs[li], bias=conv.bias, act=kind, prelu_alpha=alpha, in_scale=sc,
+                           in_shift=sh, in_add=add, in_blocked=blocked, out_blocked=out_blocked)
+            blocked = out_blocked
             last = li == len(layers) - 1
             m = out_mask if last else None
             if bn is not None:
-                aff = _bn_affine(bn, x, m)
+                aff = _bn_affine(bn, x, m, blocked=blocked)
             elif m is not None:
                 aff = ops.bn_fold(x.shape[1], mask_bc=m)
             else:

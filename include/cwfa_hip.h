@@ -197,9 +197,11 @@ typedef struct {
                                  index the shuffled output ([Co])                                         */
     int in_blocked8;          /* cwfa_conv3x3_split_f32 only: x is channel-blocked [B][Cin/8][H][W][8] (what
                                  cwfa_subnet_layer_split_f32 writes with layout bit 1); Cin % 8 == 0, no in_* */
-    int out_blocked8;         /* cwfa_conv2d_f32, 1x1 banks with 33..64 outputs, bias only: y is written
-                                 channel-blocked [B][Cout/8][H][W][8] (the first convolution of a coupling
-                                 sub-network feeding cwfa_subnet_layer_split_f32 with layout bit 0)          */
+    int out_blocked8;         /* y is written channel-blocked [B][Cout/8][H][W][8]: cwfa_conv2d_f32 for 1x1 banks
+                                 with 33..64 outputs, bias only (the first convolution of a coupling sub-network
+                                 feeding cwfa_subnet_layer_split_f32 with layout bit 0); cwfa_conv3x3_split_f32
+                                 with a bias / PReLU epilogue (the first convolution of a UNetConvBlock; its
+                                 statistics: cwfa_channel_stats_blocked8_f32, its consumer: in_blocked8)       */
 } cwfa_conv_opts;
 
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
@@ -233,6 +235,8 @@ int cwfa_conv3d_1k1_f32(const float* x, const float* w1, const float* b1, const 
 
 /* per-channel batch statistics for train-mode BatchNorm2d: stats[2*C] += (sum, sumsq) over (B,H,W), double */
 int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream);
+/* the same for a channel-blocked map [B][C/8][HW][8] (cwfa_conv_opts.out_blocked8), C % 8 == 0, 16-byte aligned */
+int cwfa_channel_stats_blocked8_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream);
 /* turn (sum,sumsq,count) or running (mean,var) into scale/shift: scale = w*rsqrt(var+eps), shift = b - mean*scale
  * stats != NULL: batch statistics (biased variance);  else running_mean / running_var.
  * mask_bc (nullable, [B*C]): per-(sample,channel) multiplier (F.dropout2d keep-mask / (1-p)); scale and shift are then

@@ -1226,6 +1226,33 @@ def test_split_layer_channel_blocked_layouts(shape):
         ops.set_precision("fp32")
 
 
+def test_unet_block_channel_blocked_intermediate():
+    """UNetConvBlock in split precision: the map between its two convolutions channel-blocked (16-byte stores in the first
+    convolution, BatchNorm statistics by cwfa_channel_stats_blocked8_f32, 16-byte staging loads + BatchNorm-on-load in the
+    second) against the NCHW form of the same kernels, and the blocked statistics kernel against the plain one."""
+    from cwfa_amd import ops, unet
+    torch.manual_seed(2)
+    blk = unet.UNetConvBlock(24, 64, True, True, activation=torch.nn.PReLU).cuda().train()
+    x = torch.randn(2, 24, 37, 50, device="cuda")
+    ops.set_precision("split_bf16")
+    try:
+        outs = []
+        for flag in (True, False):
+            ops.BLOCKED_UNET = flag
+            torch.manual_seed(0)
+            for m in blk.block:
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            with torch.no_grad():
+                outs.append(blk(x))
+        assert_close(outs[0], outs[1], 1e-6, "blocked vs NCHW intermediate")
+        y = torch.randn(2, 64, 37, 50, device="cuda")
+        assert_close(ops.channel_stats(_to_blocked(y), blocked=True), ops.channel_stats(y), 1e-12, "blocked statistics")
+    finally:
+        ops.BLOCKED_UNET = False
+        ops.set_precision("fp32")
+
+
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
