@@ -57,6 +57,18 @@ def family(key):
     return "conv2d_mfma_kernel<k%d,%s>[%s]" % (ks, "co<=32" if cout <= 32 else "co<=64" if cout <= 64 else "co>64", tag)
 
 
+# kernel family (see family()) -> substrings of the rocprofv3 kernel names it covers (tools/pmc_traffic.py averages FETCH_SIZE /
+# WRITE_SIZE over the launches of all of them; the layer kernel has one instantiation per map layout)
+ROCPROF_NAMES = {
+    "conv3x3_split_kernel[pro|prelu|||+split]": ["conv3x3_split_kernel<4, true, false, 2>", "conv3x3_split_kernel<4, false, false, 2>"],
+    "split_layer_kernel": ["split_layer_kernel<"],
+    "wino_layer_kernel": ["wino_layer_kernel<false>"],
+    "conv3x3_wino2d_kernel[|prelu|||]": ["conv3x3_wino2d_kernel<2, false, true>"],
+    "conv3x3_wino_kernel<W128>[pro|prelu|||]": ["conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, true>"],
+    "conv3x3_wino_kernel<W128>[|prelu|||]": ["conv3x3_wino_kernel<WCfg<8, 2, 2, 4>, 3, false>"],
+}
+
+
 def issued_factor(fam):
     """Matrix-core products actually issued per algorithmic multiply-add of a kernel family, and the pipe they run on.
     fp32 MFMA kernels: Winograd issues fewer (2/3 for F(2,3), 4/9 for F(2x2,3x3), 0.7 for the fused layer = nine F(2,3)

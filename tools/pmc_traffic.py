@@ -36,14 +36,14 @@ def main(out):
     b = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-experiment"]
     fetch, write = run_pmc("FETCH_SIZE", b, "f"), run_pmc("WRITE_SIZE", b, "w")
     kernels = {}
-    for fam, rname in bench.ROCPROF_NAMES.items():
-        hits = [k for k in fetch if rname in k.replace("(anonymous namespace)::", "")]
+    for fam, rnames in bench.ROCPROF_NAMES.items():
+        hits = [k for k in fetch if any(r in k.replace("(anonymous namespace)::", "") for r in rnames)]
         if not hits:
             continue
-        k = hits[0]
-        f_kb, nl = fetch[k]
-        w_kb = write.get(k, (0.0, 0))[0]
-        kernels[fam] = {"rocprof_kernel": k.replace("(anonymous namespace)::", ""), "launches": nl, "FETCH_SIZE_KB_raw": f_kb,
+        nl = sum(fetch[k][1] for k in hits)                                 # launches of all the family's instantiations
+        f_kb = sum(fetch[k][0] * fetch[k][1] for k in hits) / nl
+        w_kb = sum(write[k][0] * write[k][1] for k in hits if k in write) / max(sum(write[k][1] for k in hits if k in write), 1)
+        kernels[fam] = {"rocprof_kernels": [k.replace("(anonymous namespace)::", "") for k in hits], "launches": nl, "FETCH_SIZE_KB_raw": f_kb,
                         "WRITE_SIZE_KB": w_kb, "fetch_factor_dword_per_lane": factor.get(4),
                         "hbm_bytes_per_launch": (f_kb * factor.get(4, 1.0) + w_kb) * 1024.0}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 2 --warmup 1`; per-launch "
