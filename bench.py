@@ -42,12 +42,24 @@ SPLIT_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product 
 WINO2D_MIN = 512      # the library's "winograd_2d" default (ops.WINOGRAD_2D_DEFAULT); --wino2d overrides both
 
 
+SPLIT_SIX = True      # six bf16 products per fp32 product (False in --precision bf16); part of the split kernels' template arguments
+
+
 def family(key):
     """The kernel instantiation a conv launch runs (mirrors the dispatch in csrc/conv2d.hip / conv_wino.hip /
     conv_split_layer.hip), i.e. ONE kernel name in a rocprofv3 trace: launches of one family differ only in Cin/H/W/B."""
     ks, cin, cout, H, W, B, tag = key[:7]
     if ks == "L":
         return "split_layer_kernel" if tag.endswith("+split") else "wino_layer_kernel"
+    if tag.endswith("+split") and ks == 3:
+        # exactly the rocprofv3 name: conv3x3_split_kernel<MPW, SIX, ADD, ACT1> (csrc/conv_split3x3.hip: launch_epi)
+        pro, act, res, act2, _ = tag.split("|")
+        plain = not res and not act2
+        act1 = 2 if (plain and act == "prelu") else 0 if (plain and not act and not key[7]) else -1
+        if tag.endswith("couple+split"):
+            act1 = -2
+        return "conv3x3_split_kernel<%d, %s, %s, %d>" % (4 if cout > 128 else 2 if cout > 64 else 1, "true" if SPLIT_SIX else "false",
+                                                          "true" if key[7] else "false", act1)
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
@@ -60,7 +72,9 @@ def family(key):
 # kernel family (see family()) -> substrings of the rocprofv3 kernel names it covers (tools/pmc_traffic.py averages FETCH_SIZE /
 # WRITE_SIZE over the launches of all of them; the layer kernel has one instantiation per map layout)
 ROCPROF_NAMES = {
-    "conv3x3_split_kernel[pro|prelu|||+split]": ["conv3x3_split_kernel<4, true, false, 2>", "conv3x3_split_kernel<4, false, false, 2>"],
+    "conv3x3_split_kernel<4, true, false, 2>": ["conv3x3_split_kernel<4, true, false, 2>"],
+    "conv3x3_split_kernel<4, true, true, 2>": ["conv3x3_split_kernel<4, true, true, 2>"],
+    "conv3x3_split_kernel<4, false, false, 2>": ["conv3x3_split_kernel<4, false, false, 2>"],
     "split_layer_kernel": ["split_layer_kernel<"],
     "wino_layer_kernel": ["wino_layer_kernel<false>"],
     "conv3x3_wino2d_kernel[|prelu|||]": ["conv3x3_wino2d_kernel<2, false, true>"],
@@ -201,6 +215,8 @@ def main():
     PREC = {"split": "split_bf16", "fp32": "fp32", "bf16": "bf16"}
     ops.set_precision(PREC[a.precision])
     products = {"split": SPLIT_PRODUCTS, "bf16": 1, "fp32": SPLIT_PRODUCTS}[a.precision]
+    global SPLIT_SIX
+    SPLIT_SIX = a.precision != "bf16"
     S = 5                                                    # INN_max_down_steps (main.py:106): 4 flow steps + LRNN
     torch.manual_seed(0)
     np.random.seed(0)

@@ -1038,6 +1038,52 @@ def test_full_size_forward_nll_vs_oracle():
     assert abs(float(nll) - ref) <= 1e-5 * abs(ref)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "split_bf16"])
+def test_full_size_step_with_saturated_couplings_vs_oracle(prec):
+    """Default-init weights keep |s| small (the `_first` last convolution has gain 0.01).  Trained weights may drive the
+    couplings to their clamp: here the output convolutions of all five sub-networks of the finest step (512x512x96) are
+    scaled up until s spans the whole +-2 * 0.636 * pi/2 range of the ATAN clamp (every block then amplifies by up to e^2),
+    and the inverse and the forward pass are compared with the CPU oracle under the same bound."""
+    from cwfa_amd import CWFA, ops
+    from oracle import cwfa_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 2, with_lrnn=False, device="cuda")
+    gi, cn = conv_inn[0], cond_nets[0]
+    with torch.no_grad():
+        for m in gi.module_list:
+            net = getattr(m, "subnet", None)
+            if net is not None:
+                last = net.block72[1] if net.normal else net.block7[1]
+                last.weight.mul_(300.0 if not net.normal else 6.0)
+                last.bias.mul_(10.0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 96, 512, 512, generator=g)
+    views = torch.randn(1, 29, 512, 512, generator=g)
+    mean = 0.1 * torch.randn(1, 48, 512, 512, generator=g)
+    low = torch.randn(1, 48, 512, 512, generator=g)
+    cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
+    axes = {i: (m.axis if hasattr(m, "axis") else 1) for i, m in enumerate(gi.module_list) if hasattr(m, "perm")}
+    with torch.no_grad():
+        om_r = O.omega_net(cpu(cn.state_dict()), views)
+        (z_r, low_r), ld_r = O.flow_step(cpu(gi.state_dict()), x, [om_r, mean], False, axes)
+        x_r, ldi_r = O.flow_step(cpu(gi.state_dict()), (torch.zeros_like(low), low), [om_r, mean], True, axes)
+    # the couplings really are driven hard: the log-det per element is far from 0 and the latent spans orders of magnitude
+    assert float(ld_r.abs().max()) / (48 * 512 * 512) > 0.05, float(ld_r.abs().max()) / (48 * 512 * 512)
+    ops.set_precision(prec)
+    try:
+        with torch.no_grad():
+            om = cn(views.cuda())[-1]
+            Z, logdet = gi(x.cuda(), c=[om, mean.cuda()])
+            xi, ldi = gi([torch.zeros_like(low).cuda(), low.cuda()], c=[om, mean.cuda()], rev=True)
+    finally:
+        ops.set_precision("fp32")
+    assert_close(Z[0], z_r, TOL, f"{prec}: latent")
+    assert_close(logdet, ld_r, TOL, f"{prec}: log-det")
+    assert_close(xi, x_r, TOL, f"{prec}: inverse")
+    assert_close(ldi, ldi_r, TOL, f"{prec}: log-det of the inverse")
+
+
 def test_config4_forward_nll_pass_batch4_vs_oracle():
     """BASELINE.json configs[3] at its per-GPU shape: batch 4 of 512x512x96 volumes, the forward / NLL pass over ALL four
     flow steps with their condition nets (``CWFA.forward_nll_pass``: what bench.py's forward_nll leg times) against the CPU

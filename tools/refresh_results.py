@@ -1,44 +1,46 @@
 #!/usr/bin/env python3
-"""Re-generate the r01 v3 rows of DESIGN.md section 9 from profiles/r01_v3_* (run after copying fresh GPU results there)."""
-import csv, json, os, re
+"""Re-generate the results block of DESIGN.md section 9 from profiles/<tag>_* (run after copying fresh GPU results there):
+    python tools/refresh_results.py r02_v3"""
+import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.load(open(os.path.join(ROOT, "profiles/r01_v3_bench.json")))
-r = d["roofline"]
-rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles/r01_v3_bench_kernel_stats.csv"))))
-steps = 16                                             # prof_bench.sh: 10 timed + 3 warm-up/selection + 3 runner-up passes
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02_v3"
+P = lambda n: os.path.join(ROOT, "profiles", f"{TAG}_{n}")   # noqa: E731
+d = json.load(open(P("bench.json")))
+r, r2, dw = d["roofline"], d["roofline_second"], d["roofline_dwt"]
+rows = list(csv.DictReader(open(P("bench_kernel_stats.csv"))))
+# tools/prof_bench.sh: 10 timed steps + 3 warm-up / selection + 3 runner-up + 3 chain-event passes
+steps = 19
 tot = sum(float(x["TotalDurationNs"]) for x in rows) / steps / 1e6
-lines = ["| `%s` | %d | %.2f | %.1f |" % (x["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70],
-                                          int(x["Calls"]) // steps, float(x["TotalDurationNs"]) / steps / 1e6, float(x["Percentage"]))
-         for x in rows[:14]]
-rest = sum(float(x["TotalDurationNs"]) for x in rows[14:]) / steps / 1e6
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:72]   # noqa: E731
+lines = ["| `%s` | %.1f | %.2f | %.1f |" % (short(x["Name"]), int(x["Calls"]) / steps, float(x["TotalDurationNs"]) / steps / 1e6,
+                                          float(x["Percentage"])) for x in rows[:16]]
+rest = sum(float(x["TotalDurationNs"]) for x in rows[16:]) / steps / 1e6
 table = ("| kernel | launches / volume | ms / volume | % |\n|---|---|---|---|\n" + "\n".join(lines) +
-         "\n| (%d smaller kernels) | | %.2f | %.1f |\n| total | | %.2f | 100 |" % (len(rows) - 14, rest, 100 * rest / tot, tot))
+         "\n| (%d smaller kernels) | | %.2f | %.1f |\n| total | | %.2f | 100 |" % (len(rows) - 16, rest, 100 * rest / tot, tot))
 cb = d["cpu_baseline"]
-dom = r["kernel"].split(" (")[0]
-nshapes = len(r.get("shapes", []))
-if dom == "wino_layer_kernel":
-    kdesc = "the fused residual layer of the coupling sub-networks, 64 channels @512², 60 launches per volume"
-    tdesc = "the remaining factor is the row halo of the tile (the 3x3 reads 6 rows for 4) where it misses L2, and the filter panels."
-else:
-    kdesc = f"UNet 3×3 convs, {nshapes} shapes"
-    tdesc = "the remaining factor is the row halo of a 4-row tile and the second read by the other cout tiles where it misses L2; before the XCD-aware tile map it was 11x."
-block = f"""<!-- RESULTS:BEGIN (tools/refresh_results.py) -->
-| r01 v3 (Winograd F(2,3) / F(2×2,3×3), in-stream staging, buffer loads, MFMA Conv3d, XCD-aware tiles, materialised BatchNorm outputs) | {d['value']:.1f} | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` ({kdesc}) | {r['achieved']:.1f} ({r['frac']:.2f}; matrix pipe {r['mfma_issued_frac']:.2f}) | {d['roofline_dwt']['achieved']:.0f} ({d['roofline_dwt']['frac']:.2f}) |
+fam_rows = [x for x in rows if "conv3x3_split_kernel<4, true, false, 2>" in x["Name"] or "conv3x3_split_kernel<4, true, true, 2>" in x["Name"]]
+avg_dom = sum(float(x["TotalDurationNs"]) for x in fam_rows) / max(sum(int(x["Calls"]) for x in fam_rows), 1) / 1e6
+others = []
+for bt in ("GLOW", "AI1"):
+    f = P(f"bench_{bt}.json")
+    if os.path.exists(f):
+        g = json.load(open(f))
+        others.append(f"{bt} {g['value']:.1f} volumes/s ({g['ms_per_step']:.1f} ms; forward NLL {g.get('forward_nll', {}).get('value', float('nan')):.1f})")
+fw = d.get("forward_nll", {})
+block = f"""<!-- RESULTS:BEGIN (tools/refresh_results.py {TAG}) -->
+| {TAG.replace('_', ' ')} (split-bf16 fp32-equivalent convolutions on `v_mfma_f32_16x16x32_bf16`, fused split layer, channel-blocked sub-network maps, 16-byte chain kernels) | **{d['value']:.1f}** | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` ({len(r.get('shapes', []))}+ shapes of the UNet, {r['launches_timed'] // d['steps']} launches per volume, {100 * r['share_of_conv_time']:.0f} % of the conv time) | {r['algorithmic_tflops']:.0f} algorithmic = {r['achieved']:.0f} issued of 2500 bf16: **{r['frac']:.2f}** | in-path chain {dw['achieved']:.0f} ({dw['frac']:.2f}); largest level {dw['largest_level']['GBps']:.0f} ({dw['largest_level']['GBps'] / 8000:.2f}) |
 
-CPU baseline (oracle, torch CPU, all host cores): {cb['value']:.4f} volumes/s on {cb['cores']} cores ({cb['sample']}) — GPU/CPU = {d['value'] / cb['value']:.0f}×; reported for context, the roofline fraction is the figure of merit.
+Same line: runner-up `{r2['kernel'].split(' (')[0]}` {r2['algorithmic_tflops']:.0f} TF/s algorithmic, frac **{r2['frac']:.2f}** ({1e3 * r2['avg_launch_ms']:.1f} µs per launch, 60 launches per volume); plain fp32 MFMA kernels (`fp32_mfma`) {d['fp32_mfma']['value']:.1f} volumes/s; bf16 configuration (`bf16`, BASELINE configs[4]) {d['bf16']['value']:.1f}; forward NLL (configs[3], batch 4 per GPU) {fw.get('value', float('nan')):.1f} volumes/s with its chain at {fw.get('chain_fwd', {}).get('frac', float('nan')):.2f} of the HBM peak; training iteration {d['experiment_train_step']['value']:.2f} volumes/s.  Other block types (`bench.py --block-type`, `profiles/{TAG}_bench_<type>.json`): {'; '.join(others)}.  Standalone wavelet kernels (not launched by the path): four inverse depth-Haar levels {dw['standalone_haar']['achieved']:.0f} GB/s ({dw['standalone_haar']['frac']:.2f}); one-pass 2×2×2 Haar tile {dw['haar3d_tile']['achieved']:.0f} GB/s ({dw['haar3d_tile']['frac']:.2f}).
 
-Dominant kernel traffic (`profiles/r01_v3_pmc_traffic.json`): {r['traffic'] / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (input once + output once) — {tdesc}  `avg_launch_ms` {r['avg_launch_ms']:.3f} (HIP events, bench.py) vs {float(rows[0]['AverageNs']) / 1e6:.3f} (rocprofv3 average of the same kernel).
+CPU baseline (oracle, torch CPU): {cb['value']:.4f} volumes/s on {cb['cores']} threads of {cb.get('cpu_model', '?')} ({cb['sample']}) — GPU/CPU = {d['value'] / cb['value']:.0f}×; reported for context, the roofline fraction is the figure of merit.
 
-Per-kernel time per volume, r01 v3 (rocprofv3 `--kernel-trace --stats`, `profiles/r01_v3_bench_kernel_stats.csv`):
+Dominant kernel traffic (`profiles/{TAG}_pmc_traffic.json`): {(r['traffic'] or 0) / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (input once + output once): every 256-channel cout tile reads the input again (1 / 2 / 4 tiles for 256 / 512 / 1024 outputs) plus the 10/8 × 34/32 halo of a tile, where it misses that XCD's L2; the layer kernel {(r2['traffic'] or 0) / 1e6:.0f} MB vs {r2['algorithmic_bytes_per_launch'] / 1e6:.0f} MB.  `avg_launch_ms` {r['avg_launch_ms']:.3f} (HIP events, bench.py: the 9 launches per volume with a load-side prologue) vs {avg_dom:.3f} (rocprofv3, call-weighted average of the two instantiations `conv3x3_split_kernel<4, true, false, 2>` and `<4, true, true, 2>` = 10 launches per volume: the nine above plus the UNet's first convolution, 6 → 256 channels, ≈ 0.3 ms, which runs the same instantiation without a prologue).
+
+Per-kernel time per volume (rocprofv3 `--kernel-trace --stats` over `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-experiment`, `profiles/{TAG}_bench_kernel_stats.csv`; {steps} volumes in the trace):
 {table}
 <!-- RESULTS:END -->"""
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-if "<!-- RESULTS:BEGIN" in s:
-    s = re.sub(r"<!-- RESULTS:BEGIN.*?<!-- RESULTS:END -->", lambda m: block, s, flags=re.S)
-else:
-    a = s.index("| r01 v3 (Winograd F(2,3)")
-    b = s.index("## 10. What comes next")
-    s = s[:a] + block + "\n\n" + s[b:]
+s = re.sub(r"<!-- RESULTS:BEGIN.*?<!-- RESULTS:END -->", lambda m: block, s, flags=re.S)
 open(p, "w").write(s)
 print("DESIGN.md section 9 refreshed:", round(d["value"], 2), "vol/s")
