@@ -1055,7 +1055,7 @@ def test_full_size_step_with_saturated_couplings_vs_oracle(prec):
             net = getattr(m, "subnet", None)
             if net is not None:
                 last = net.block72[1] if net.normal else net.block7[1]
-                last.weight.mul_(300.0 if not net.normal else 6.0)
+                last.weight.mul_(1000.0 if not net.normal else 20.0)
                 last.bias.mul_(10.0)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(1, 96, 512, 512, generator=g)
@@ -1068,8 +1068,8 @@ def test_full_size_step_with_saturated_couplings_vs_oracle(prec):
         om_r = O.omega_net(cpu(cn.state_dict()), views)
         (z_r, low_r), ld_r = O.flow_step(cpu(gi.state_dict()), x, [om_r, mean], False, axes)
         x_r, ldi_r = O.flow_step(cpu(gi.state_dict()), (torch.zeros_like(low), low), [om_r, mean], True, axes)
-    # the couplings really are driven hard: the log-det per element is far from 0 and the latent spans orders of magnitude
-    assert float(ld_r.abs().max()) / (48 * 512 * 512) > 0.05, float(ld_r.abs().max()) / (48 * 512 * 512)
+    # the couplings really are driven hard: five blocks of e^{+-s}, |s| up to 2, spread a unit-variance input over orders of magnitude
+    assert float(z_r.abs().max()) > 100.0 and float(z_r.std()) > 3.0, (float(z_r.abs().max()), float(z_r.std()))
     ops.set_precision(prec)
     try:
         with torch.no_grad():
