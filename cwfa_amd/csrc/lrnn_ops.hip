@@ -17,7 +17,18 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     if (vec_ok && (lo & 3) == 0) {
         const int64_t n4 = (hi - lo) >> 2;
         const cs_f4* p4 = reinterpret_cast<const cs_f4*>(p + lo);
-        for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        int64_t i = threadIdx.x;
+        for (; i + 3 * (int64_t)blockDim.x < n4; i += 4 * (int64_t)blockDim.x) {        // four 16-byte loads in flight per thread
+            cs_f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[i + u * (int64_t)blockDim.x];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += ((double)v[u][0] + (double)v[u][1]) + ((double)v[u][2] + (double)v[u][3]);
+                q += ((double)v[u][0] * v[u][0] + (double)v[u][1] * v[u][1]) + ((double)v[u][2] * v[u][2] + (double)v[u][3] * v[u][3]);
+            }
+        }
+        for (; i < n4; i += blockDim.x) {
             const cs_f4 v = p4[i];
             s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
             q += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
@@ -46,7 +57,11 @@ extern "C" int cwfa_channel_stats_f32(const float* x, double* stats, int B, int 
     CWFA_REQUIRE(x && stats, CWFA_E_INVAL, "cwfa_channel_stats_f32: null pointer");
     CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C <= 65535 && B <= 65535, CWFA_E_SHAPE, "cwfa_channel_stats_f32: bad shape");
     if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
-    int splits = (int)((HW + 256 * 16 - 1) / (256 * 16));          // >= 16 elements per thread
+    // enough blocks to fill the chip several times over (256 CUs x 8 resident blocks), but as few atomics and as long
+    // streams per block as that allows: ~4096 blocks in all, >= 16 elements per thread
+    int splits = (int)((HW + 256 * 16 - 1) / (256 * 16));
+    const int64_t want = (4096 + (int64_t)C * B - 1) / ((int64_t)C * B);
+    if (splits > want) splits = (int)want;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
     const int vec_ok = (HW & 3) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
@@ -199,6 +214,39 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     y[(int64_t)bc * n + i] = m;
 }
 
+// exact 2x2 windows (H = 2 Ho, W = 2 Wo, W % 4 == 0, 16-byte aligned rows): a thread owns two output pixels = 4 x 2 inputs,
+// 16-byte loads / stores (the UNet's pooling, unet.py:79, always has this shape)
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ full,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int C,
+                                                         int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1, wq = W >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Ho * wq) return;
+    const int bc = blockIdx.y, c = bc % C;
+    const int oy = (int)(i / wq), q = (int)(i % wq);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const int64_t o = (int64_t)bc * H * W + (int64_t)(2 * oy) * W + 4 * q;
+    cs_f4 r0 = *reinterpret_cast<const cs_f4*>(x + o), r1 = *reinterpret_cast<const cs_f4*>(x + o + W);
+    if (scale) {
+        r0 = r0 * sc + sh;
+        r1 = r1 * sc + sh;
+    }
+    if (full) {
+        *reinterpret_cast<cs_f4*>(full + o) = r0;
+        *reinterpret_cast<cs_f4*>(full + o + W) = r1;
+    }
+    float m[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {               // same visiting order as the generic kernel: (0,0) (0,1) (1,0) (1,1); NaN propagates
+        float a = -INFINITY;
+        const float v4[4] = {r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a = (v4[j] > a || v4[j] != v4[j]) ? v4[j] : a;
+        m[k] = a;
+    }
+    *reinterpret_cast<float2*>(y + (int64_t)bc * Ho * Wo + (int64_t)oy * Wo + 2 * q) = make_float2(m[0], m[1]);
+}
+
 extern "C" int cwfa_maxpool_f32(const float* x, float* y, float* full, const float* scale, const float* shift, int B, int C,
                                 int H, int W, int Ho, int Wo, void* stream) {
     CWFA_REQUIRE(x && y, CWFA_E_INVAL, "cwfa_maxpool_f32: null pointer");
@@ -208,6 +256,13 @@ extern "C" int cwfa_maxpool_f32(const float* x, float* y, float* full, const flo
     CWFA_REQUIRE((int64_t)B * C <= 65535, CWFA_E_SHAPE, "cwfa_maxpool_f32: B*C too large");
     if (B == 0 || C == 0) return CWFA_OK;
     const int64_t n = (int64_t)Ho * Wo;
+    if (H == 2 * Ho && W == 2 * Wo && (W & 3) == 0 && cwfa_aligned16(x) && (!full || cwfa_aligned16(full)) &&
+        (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+        hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)((n / 2 + 255) / 256), B * C), dim3(256), 0, (hipStream_t)stream, x, y, full,
+                           scale, shift, C, H, W);
+        CWFA_LAUNCH_CHECK("cwfa_maxpool_f32");
+        return CWFA_OK;
+    }
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((n + 255) / 256), B * C), dim3(256), 0, (hipStream_t)stream, x, y, full,
                        scale, shift, C, H, W, Ho, Wo);
     CWFA_LAUNCH_CHECK("cwfa_maxpool_f32");

@@ -1217,6 +1217,24 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
         assert_close(got[k], want[k], 5e-6, f"split 3x3 {k}")
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 16, 24, 8, 12), (1, 3, 10, 14, 5, 7), (1, 4, 9, 13, 4, 6), (1, 64, 128, 128, 64, 64)])
+def test_maxpool_with_affine_vs_torch(shape):
+    """cwfa_maxpool_f32 (adaptive max-pool of the BatchNorm-normalised map + the normalised full map, unet.py:79): the 16-byte
+    2x2 fast path (W % 4 == 0), the generic window kernel (W % 4 != 0, overlapping adaptive windows) -- against ATen, bit-exact."""
+    from cwfa_amd import ops
+    B, Cc, H, W, Ho, Wo = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    norm = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    ref = torch.nn.functional.adaptive_max_pool2d(norm, (Ho, Wo))
+    y, full = ops.maxpool(x.cuda(), Ho, Wo, sc.cuda(), sh.cuda(), want_full=True)
+    assert torch.equal(full.cpu(), norm) and torch.equal(y.cpu(), ref)
+    y2 = ops.maxpool(x.cuda(), Ho, Wo)
+    y2 = y2[0] if isinstance(y2, tuple) else y2
+    assert torch.equal(y2.cpu(), torch.nn.functional.adaptive_max_pool2d(x, (Ho, Wo)))
+
+
 def _to_blocked(t):
     B, Cc, H, W = t.shape
     return t.view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, Cc, H, W)
