@@ -337,6 +337,17 @@ class _CatStepPlan:
         -> (s_raw, t, t_neg_div_sqrt2) replaces the block's own sub-network call (the training path keeps a tape)."""
         stages, pending = [], None
         seq = list(reversed(self.chain)) if rev else self.chain
+        if coefficients is None:
+            # the blocks' sub-networks are independent of each other (their inputs are the conditions): layer by layer in
+            # grouped launches where that form applies (networks.grouped_affine_parts)
+            cats = [obj for kind, obj in seq if kind == "cat"]
+            grouped = None
+            if len(cats) > 1 and all(hasattr(n.module.subnet, "affine_parts") for n in cats):
+                from ...networks import grouped_affine_parts
+                grouped = grouped_affine_parts([(n.module.subnet, [cond_of[cn] for cn in n.conditions], n.module.channels) for n in cats])
+            if grouped is not None:
+                pre = {id(n.module): r for n, r in zip(cats, grouped)}
+                coefficients = lambda module, c: pre[id(module)]      # noqa: E731
         for kind, obj in seq:
             if kind == "perm":
                 if pending is not None:                                 # two permutations in a row: identity affine

@@ -335,13 +335,15 @@ class AllInOneBlock(InvertibleModule):
         x1, x2 = v[:, :l1], v[:, l1:]
         parts = [x1, *c] if self.conditional else [x1]
         u = v if (rev or self.reverse_pre_permute) else ops.concat_channels([x1, x2])   # a tensor we own: x2 half is overwritten
-        fused = (not self.GIN and hasattr(self.subnet, "couple") and
-                 self.subnet.couple(parts, x2, u[:, l1:], "TANH", self.clamp, 0.1, rev, acc))   # `a *= 0.1`, :213
-        if not fused:
+        # the coupling from the accumulators of the sub-network's last convolution where that form applies (`a *= 0.1`, :213)
+        if (not self.GIN and hasattr(self.subnet, "couple") and
+                self.subnet.couple(parts, x2, u[:, l1:], "TANH", self.clamp, 0.1, rev, acc)):
+            st = None
+        else:
             s_raw, t, _ = subnet_st(self.subnet, parts, l2)
             st = ops.stage(s_raw, t, "TANH", self.clamp, pre_scale=0.1)
-        if fused:
-            pass
+        if st is None:
+            pass                                        # done: x2 half of u written, log-det accumulated
         elif self.GIN:
             # s <- s - mean_{C,H,W}(s) per sample (:218-219): sum s with one reduction pass (affine of a zero input), then the
             # plain affine and a per-sample factor exp(-+mean) on the coupled half; log-det of the coupling is 0

@@ -108,6 +108,8 @@ SIGNATURES = {
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),
     "cwfa_subnet_layer_split_pack_f32": (i, [p, p, p, p]),
     "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, i, p]),
+    "cwfa_subnet_layer_split_max_problems": (i, []),
+    "cwfa_subnet_layer_split_group_f32": (i, [p, p, p, p, p, i, i, i, i, i64, i64, i, p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

@@ -50,8 +50,9 @@ constexpr int WSL = 3 * 4 * 64 * 16;        // bytes of one weight slice (12 288
 constexpr int NSL = 20;                     // 18 slices of the 3x3 bank + 2 of the 1x1 bank
 constexpr int OFF_W = 2 * XB;
 constexpr int OFF_DUMP = OFF_W + 3 * WSL;   // 4 KB: where waves 4..7 send their second (out-of-range, zero) slice DMA
-constexpr int OFF_BIAS = OFF_DUMP + 4096;   // b3[64], b1[64]
-constexpr int LDS_BYTES = OFF_BIAS + 512;   // 161 280
+constexpr int MAXP = 5;                     // problems (filter banks) per launch: what the rest of the 160 KB holds in biases
+constexpr int OFF_BIAS = OFF_DUMP + 4096;   // [problem][b3[64], b1[64]]
+constexpr int LDS_BYTES = OFF_BIAS + MAXP * 512;   // 163 328
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int NE = 2 * XR * XC;             // 1224 staging entries (k half, row, col) per chunk
 
@@ -64,6 +65,8 @@ struct LParams {
     int B, H, W, tiles_x, tiles_y, ntiles;
     int64_t x_bs, y_bs;
     int in_blocked, out_blocked;      // layout of x / y: 0 = NCHW planes, 1 = [C/8][H][W][8] (see the header comment)
+    int nprob, spp;                   // grouped launch: sample b belongs to problem b / spp, which has its own packed image (wp + problem *
+                                      // NSL * WSL) and biases (b3 / b1 + problem * 64); nprob = 1: one bank for the whole batch
 };
 
 template <int K>
@@ -177,19 +180,21 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     };
 
     // ---- weight slices: 12 x 1 KB; every wave issues two DMA instructions (waves 4..7: the second into the dump area)
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, NSL * WSL, 0x00020000);
-    auto dma_w = [&](int slice, int slot) {
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, p.nprob * NSL * WSL, 0x00020000);
+    // `wb`: byte offset of the problem's packed image (scalar)
+    auto dma_w = [&](int slice, int slot, int wb) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + OFF_W + slot * WSL + wave * 1024), 16, (unsigned)tid * 16u,
-                                                 slice * WSL, 0, 0);
+                                                 wb + slice * WSL, 0, 0);
         char* d2 = lds + (wave < 4 ? OFF_W + slot * WSL + 8192 + wave * 1024 : OFF_DUMP + (wave - 4) * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)d2, 16, wave < 4 ? 8192u + (unsigned)tid * 16u : OOB, slice * WSL, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)d2, 16, wave < 4 ? 8192u + (unsigned)tid * 16u : OOB, wb + slice * WSL, 0, 0);
     };
+    auto problem_of = [&](int b) { return p.nprob > 1 ? b / p.spp : 0; };
     auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
 
     const int alane = OFF_W + (g * 64 + c16) * 16;                            // + slot*WSL + (q*256 + mt*16)*16
     const int blane = (g & 1) * KHB + ((2 * wave) * XC + c16) * 16;           // + unit_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
     const bool sel = (g >> 1) != 0;                                           // lane groups 2, 3 read the step's second unit
-    const f32x4* bias4 = reinterpret_cast<const f32x4*>(lds + OFF_BIAS);     // [b3 16 x 4][b1 16 x 4]
+    const f32x4* bias_all = reinterpret_cast<const f32x4*>(lds + OFF_BIAS);  // per problem: [b3 16 x 4][b1 16 x 4]
 
     f32x4 acc[4][4];
     bf16x8 A[2][3], Bq[4][3];
@@ -218,7 +223,10 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     auto bbase_of = [&](int offA, int offB) { return blane + (sel ? offB : offA); };
 
     // ---------------------------------------------------------------------------------------------- prologue
-    if (tid < 128) reinterpret_cast<float*>(lds + OFF_BIAS)[tid] = tid < 64 ? p.b3[tid] : p.b1[tid - 64];
+    for (int e = tid; e < p.nprob * 128; e += 512) {
+        const int pr = e >> 7, j = e & 127;
+        reinterpret_cast<float*>(lds + OFF_BIAS)[e] = j < 64 ? p.b3[pr * 64 + j] : p.b1[pr * 64 + j - 64];
+    }
     int tile = blockIdx.x;
     int tb, row0, col0;
     tile_coords(tile, tb, row0, col0);
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     entry_offsets(true, row0, col0, fo_c);
     sfor<3>([&](auto kc) { load_entry(xa[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 0); });
     sfor<3>([&](auto kc) { load_entry(xb[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 1); });
-    dma_w(0, 0);
+    int wb_cur = problem_of(tb) * (NSL * WSL);
+    dma_w(0, 0, wb_cur);
     sfor<3>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], 0); });
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -246,6 +255,8 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         const float* xs_next = p.x + (int64_t)nb * p.x_bs;
         entry_offsets(has_next, nrow0, ncol0, fo_n);
 
+        const int wb_next = problem_of(nb) * (NSL * WSL);
+        const f32x4* bias4 = bias_all + (wb_cur / (NSL * WSL)) * 32;
         // accumulators start from the conv bias (channel mt*16 + 4g + r)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -263,8 +274,8 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             // INSIDE the MFMA stream, after the first m-tile: in a burst right behind the barrier all eight waves stood in
             // their issue cost (~100 cycles per DMA instruction) at once with the matrix pipe idle
             auto issue_memory = [&]() {
-                if constexpr (S == 0) dma_w(1, s1);             // (late by one step: the 1x1 phase counts as one)
-                dma_w(S + 2, s2);
+                if constexpr (S == 0) dma_w(1, s1, wb_cur);     // (late by one step: the 1x1 phase counts as one)
+                dma_w(S + 2, s2, wb_cur);
                 if constexpr (P >= 2 && P <= 4) {               // even chunk 2*PER+2 (PER = 1: chunk 0 of the next tile)
                     constexpr int k = P - 2;
                     if constexpr (PER == 0) load_entry(xa[k], xs_cur, fo_c[k], 2);
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         // ------------------------------------------------------------------------------------------ 1x1 + epilogue
         {
             const int sw0 = cs, sw1 = next_slot(cs), sn0 = next_slot(sw1);         // W1 slices, next tile's slice 0
-            dma_w(0, sn0);
+            dma_w(0, sn0, wb_next);
             const auto rx = rsrc_of(p.x + (int64_t)tb * p.x_bs);
             const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)tb * p.y_bs, 0, 64 * plane, 0x00020000);
             // offsets of this lane's (row, col) in the two layouts: NCHW: channel 4 g (+ 16 mt + r planes in the scalar offset);
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             }
         }
         tb = nb; row0 = nrow0; col0 = ncol0;
+        wb_cur = wb_next;
         xs_cur = xs_next;
 #pragma unroll
         for (int k = 0; k < 3; ++k) fo_c[k] = fo_n[k];
@@ -500,8 +512,26 @@ extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1
     return CWFA_OK;
 }
 
+static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream);
+
 extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                            int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream) {
+    return layer_launch(x, packed, b3, b1, y, B, H, W, x_bs, y_bs, layout, 1, B > 0 ? B : 1, stream);
+}
+
+extern "C" int cwfa_subnet_layer_split_max_problems(void) { return MAXP; }
+
+extern "C" int cwfa_subnet_layer_split_group_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int nprob,
+                                                 int samples_per_problem, int H, int W, int64_t x_bs, int64_t y_bs, int layout,
+                                                 void* stream) {
+    CWFA_REQUIRE(nprob >= 1 && nprob <= MAXP && samples_per_problem >= 1, CWFA_E_SHAPE,
+                 "cwfa_subnet_layer_split_group_f32: 1 <= nprob <= %d, samples_per_problem >= 1", MAXP);
+    return layer_launch(x, packed, b3, b1, y, nprob * samples_per_problem, H, W, x_bs, y_bs, layout, nprob, samples_per_problem, stream);
+}
+
+static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream) {
     CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);
     CWFA_REQUIRE(!(layout & 1) || cwfa_aligned16(x), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input must be 16-byte aligned");
     CWFA_REQUIRE(!(layout & 2) || cwfa_aligned16(y), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output must be 16-byte aligned");
@@ -518,6 +548,8 @@ extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, c
     p.B = B; p.H = H; p.W = W; p.x_bs = x_bs; p.y_bs = y_bs;
     p.in_blocked = layout & 1;
     p.out_blocked = (layout >> 1) & 1;
+    p.nprob = nprob;
+    p.spp = spp;
     p.tiles_x = (W + TC - 1) / TC;
     p.tiles_y = (H + TR - 1) / TR;
     const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * B;

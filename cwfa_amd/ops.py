@@ -597,6 +597,36 @@ def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False, layout=0):
     return out
 
 
+def subnet_layer_group(x, packed, b3, b1, nprob, layout=0):
+    """``nprob`` independent layers of the same shape in ONE persistent launch (cwfa_subnet_layer_split_group_f32):
+    x [nprob * spp, 64, H, W] (sample b belongs to problem b // spp), ``packed`` the nprob split images back to back (uint8),
+    ``b3`` / ``b1`` [nprob, 64].  Returns y with x's shape (memory order per ``layout``, see subnet_layer)."""
+    L = _lib.lib()
+    x, xbs = planes(x, "x")
+    Bt, Cc, H, W = x.shape
+    if Cc != 64 or Bt % nprob or nprob > L.cwfa_subnet_layer_split_max_problems():
+        raise ValueError(f"subnet_layer_group: {Bt} samples of {Cc} channels do not split into {nprob} problems")
+    if packed.numel() != nprob * L.cwfa_subnet_layer_split_packed_bytes() or b3.numel() != nprob * 64 or b1.numel() != nprob * 64:
+        raise ValueError("subnet_layer_group: packed images / biases do not match nprob")
+    out = torch.empty((Bt, 64, H, W), dtype=torch.float32, device=x.device)
+    rec = conv_event_sink
+    if rec is not None:
+        key = ("L", 64, 64, H, W, Bt, "layer+split", False)
+        if rec.want(key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+    check(L.cwfa_subnet_layer_split_group_f32(_p(x), _p(packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), nprob, Bt // nprob, H, W,
+                                              xbs, 64 * H * W, int(layout), _stream()), "subnet_layer_split_group")
+    if rec is not None and rec.want(key):
+        e1.record()
+        rec.add(key, e0, e1)
+    return out
+
+
+GROUP_LAYERS = False         # True: the k-th residual layers of the five independent sub-networks of a CAT step in ONE grouped launch
+#                              (networks.grouped_affine_parts); built and tested, measured 46.3 vs 46.4 volumes/s: no gain, left off
+
+
 # ------------------------------------------------------------------------------------------------ backward of the sub-networks
 _wgrad_ws = {}
 

@@ -325,6 +325,14 @@ int64_t cwfa_subnet_layer_split_packed_bytes(void);
 int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream);
 int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H,
                                 int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
+/* Grouped form: `nprob` (<= cwfa_subnet_layer_split_max_problems()) independent layers of the same shape in ONE persistent launch --
+ * x / y [nprob * samples_per_problem, 64, H, W], sample b belongs to problem b / samples_per_problem, `packed` holds the nprob
+ * images back to back, b3 / b1 are [nprob][64].  The five sub-networks of a CAT step are independent of each other
+ * (coupling_layers.py:475-500: their inputs are the conditions), so their k-th layers run as one launch: at batch 1 a launch
+ * is only two tiles per CU, and its un-overlapped first fill and last epilogue cost ~10 %. */
+int cwfa_subnet_layer_split_max_problems(void);
+int cwfa_subnet_layer_split_group_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int nprob,
+                                      int samples_per_problem, int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
 /* layout: bit 0 = x, bit 1 = y is CHANNEL-BLOCKED, [B][8 blocks][H][W][8 channels] (same size and batch strides as NCHW, 16-byte
  * aligned), instead of NCHW planes.  The maps between the layers of one sub-network are private to it; blocked, a staging entry
  * of the kernel (8 channels of a pixel) is two 16-byte loads instead of eight 4-byte ones and the four channels a lane holds for

@@ -1290,6 +1290,41 @@ def test_split_layer_channel_blocked_layouts(shape):
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_grouped_subnet_layers_equal_the_separate_launches(B):
+    """The five sub-networks of a CAT step with their k-th residual layers in ONE persistent launch each
+    (cwfa_subnet_layer_split_group_f32: per-problem filter banks and biases) against one launch per sub-network and layer --
+    the same kernel arithmetic, bit-identical -- forward and inverse, ragged tiles, batch > 1."""
+    from cwfa_amd import CWFA, ops
+    torch.manual_seed(1)
+    np.random.seed(1)
+    conv_inn, cond_nets = CWFA.build_networks(16, 40, 2, with_lrnn=False, cond_chans=4, device="cuda")    # 64 internal channels
+    gi = conv_inn[0]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 16, 40, 40, generator=g).cuda()
+    c = [torch.randn(B, 8, 40, 40, generator=g).cuda(), 0.1 * torch.randn(B, 8, 40, 40, generator=g).cuda()]
+    low = torch.randn(B, 8, 40, 40, generator=g).cuda()
+    calls = []
+    real = ops.subnet_layer_group
+    ops.set_precision("split_bf16")
+    try:
+        outs = []
+        for flag in (True, False):
+            ops.GROUP_LAYERS = flag
+            ops.subnet_layer_group = lambda *a, **k: (calls.append(flag), real(*a, **k))[1]
+            with torch.no_grad():
+                (z, lo), j = gi(x, c=c)
+                xi, ji = gi([None, low], c=c, rev=True)
+            outs.append((z, lo, j, xi, ji))
+        assert calls == [True] * 6, calls                      # three grouped launches per direction, none when switched off
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        ops.subnet_layer_group = real
+        ops.GROUP_LAYERS = False
+        ops.set_precision("fp32")
+
+
 def test_unet_block_channel_blocked_intermediate():
     """UNetConvBlock in split precision: the map between its two convolutions channel-blocked (16-byte stores in the first
     convolution, BatchNorm statistics by cwfa_channel_stats_blocked8_f32, 16-byte staging loads + BatchNorm-on-load in the
