@@ -173,7 +173,8 @@ class AffineCouplingOneSided(_BaseCouplingBlock):
         x0 = x[0]
         l1 = self.split_len1
         x1, x2 = x0[:, :l1], x0[:, l1:]
-        out = ops.concat_channels([x1, x2])           # x1 passes through; x2 half is overwritten below
+        out = torch.empty(x0.shape, dtype=torch.float32, device=x0.device)
+        ops.copy_channels(x1, out[:, :l1])            # x1 passes through; the x2 half is written by the coupling below
         acc = new_logdet(x0)
         if not (self.clamp_kind is not None and hasattr(self.subnet, "couple") and
                 self.subnet.couple(self._cond(x1, c), x2, out[:, l1:], self.clamp_kind, self.clamp, 1.0, rev, acc)):
@@ -334,7 +335,11 @@ class AllInOneBlock(InvertibleModule):
             v = x0
         x1, x2 = v[:, :l1], v[:, l1:]
         parts = [x1, *c] if self.conditional else [x1]
-        u = v if (rev or self.reverse_pre_permute) else ops.concat_channels([x1, x2])   # a tensor we own: x2 half is overwritten
+        if rev or self.reverse_pre_permute:
+            u = v                                       # a tensor we own: its x2 half is overwritten in place
+        else:
+            u = torch.empty(x0.shape, dtype=torch.float32, device=x0.device)
+            ops.copy_channels(x1, u[:, :l1])            # only the passive half is copied; the coupling writes the other one
         # the coupling from the accumulators of the sub-network's last convolution where that form applies (`a *= 0.1`, :213)
         if (not self.GIN and hasattr(self.subnet, "couple") and
                 self.subnet.couple(parts, x2, u[:, l1:], "TANH", self.clamp, 0.1, rev, acc)):

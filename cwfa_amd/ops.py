@@ -1002,6 +1002,18 @@ def set_precision(mode):
     set_option("split_bf16", 0 if mode == "fp32" else 2)
 
 
+def copy_channels(src, dst):
+    """dst[...] = src for [B,c,H,W] views with contiguous planes (channel slices of NCHW tensors): one strided plane-copy launch."""
+    L = _lib.lib()
+    s_, sbs = planes(src, "src")
+    d_, dbs = planes(dst, "dst")
+    if d_.data_ptr() != dst.data_ptr() or tuple(src.shape) != tuple(dst.shape):
+        raise ValueError("copy_channels: dst must be a [B,c,H,W] view with contiguous planes of src's shape")
+    B, Cc, H, W = s_.shape
+    check(L.cwfa_channel_affine_f32(_p(s_), _p(dst), None, None, 0, None, None, B, Cc, H * W, sbs, dbs, _stream()), "copy_channels")
+    return dst
+
+
 def concat_channels(parts):
     """torch.cat(parts, 1) through the strided plane-copy kernel (coupling_layers.py:74-87 materialise this too)."""
     L = _lib.lib()
