@@ -734,7 +734,7 @@ int fill_params(ConvParams& p, const char* name, const float* x, const float* w_
 }
 
 // ------------------------------------------------------------------------------------------------ split-bf16 1x1 GEMM
-// EXPERIMENTAL, opt-in (cwfa_set_option("split_bf16", 1)): 1x1 convolutions / ConvTranspose2d(k2,s2) with >= 128 output
+// (ops.set_precision("split_bf16") / "bf16"; the benchmark's arithmetic): 1x1 convolutions / ConvTranspose2d(k2,s2) with >= 128 output
 // channels as an fp32-ACCURATE GEMM on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16
 // pieces (v = v1 + v2 + v3, 24 mantissa bits), the six products with i + j <= 4 are accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate / 6 products = 2.7x), error = fp32-level.

@@ -94,8 +94,10 @@ def reset_perm(network):
 class wavelet_flow_subnetwork(nn.Module):
     """1x1(c_in->n) -> 3 x [3x3(n->n), ELU, 1x1(n->n), +residual, ELU] -> 3x3(n->c_out).  networks.py:586-671.
 
-    HIP execution: every conv is the MFMA implicit-GEMM kernel with the ELU / residual / ELU fused in its epilogue
-    (5 launches... 8 launches per sub-network: 1 + 3x2 + 1).  ``normal=False`` (the ``_first`` variant) takes
+    HIP execution: the 1x1 (direct MFMA kernel), three fused layer launches (3x3 -> ELU -> 1x1 -> +x -> ELU in one kernel:
+    fp32 Winograd, or both convolutions split-bf16 with channel-blocked maps in between) and the output 3x3 -- which, for
+    the data-dependent block types, applies the coupling in its epilogue (``couple``): 5 launches per sub-network.
+    ``normal=False`` (the ``_first`` variant) takes
     cat(mean, omega): the conv stack sees only the omega half and the mean half is passed through as ``-mean/sqrt(2)``.
     """
 

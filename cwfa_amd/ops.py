@@ -336,7 +336,7 @@ class PackedConv:
     def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
         self.transposed, self.version, self.src_ptr = transposed, version, src_ptr
-        self.split = split          # weights held as three bf16 pieces for the split-bf16 GEMM (opt-in, see set_option)
+        self.split = split          # weights held as three bf16 pieces for the split-bf16 kernels (set_precision)
         self.epoch = _pack_epoch    # set_option() generation this image was built under (caches re-pack on a change)
 
 
@@ -993,9 +993,11 @@ def set_option(name, value):
 
 
 def set_precision(mode):
-    """"fp32" (default) | "split_bf16" (fp32-accurate: three bf16 pieces per operand, six products) | "bf16" (BASELINE.json
-    configs[4]: the heavy convolutions -- 1x1 / transposed >= 128 outputs, 3x3 >= 192 outputs, the 64-channel fused layers --
-    take plain bf16 operands with fp32 accumulation; wavelets, couplings, permutations and the small convs stay fp32)."""
+    """"fp32" (library default: plain fp32 MFMA / Winograd kernels) | "split_bf16" (the benchmark's arithmetic, fp32-equivalent:
+    three bf16 pieces per operand, six products, fp32 accumulation) | "bf16" (BASELINE.json configs[4]: the same kernels with ONE
+    product, i.e. plain bf16 operands and fp32 accumulation).  The split / bf16 kernels take: 1x1 and transposed convolutions with
+    >= 128 outputs, 3x3 convolutions with >= SPLIT_3X3_MIN_COUT outputs, the 64-channel fused layers; wavelets, couplings,
+    permutations, the Conv3d of the condition nets and the remaining small convolutions stay fp32."""
     if mode not in ("fp32", "split_bf16", "bf16"):
         raise ValueError(f"set_precision: unknown mode {mode!r}")
     set_option("split_products", 1 if mode == "bf16" else 6)

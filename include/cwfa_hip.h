@@ -269,7 +269,7 @@ int cwfa_scale_channels_f32(const float* x, const float* scale_bc, float* y, int
 int cwfa_axpby_f32(const float* x, const float* z, float a, float b, float* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * EXPERIMENTAL: fp32-accurate 1x1 / 3x3 convolution and ConvTranspose2d(k2,s2) on the bf16 matrix pipe (same reference ops
+ * fp32-equivalent 1x1 / 3x3 convolution and ConvTranspose2d(k2,s2) on the bf16 matrix pipe (same reference ops
  * as cwfa_conv2d_f32 with ks = 1 or 3, tiles of 256 output channels: nn.Conv2d 1x1 networks.py:488-492, nn.ConvTranspose2d unet.py:166).  Each fp32 operand is
  * split exactly into three bf16 pieces, six partial products are accumulated in fp32.
  *   cwfa_split_workspace_bytes / cwfa_split_input_f32 : x [B,Cin,HW] (+ per-channel or per-(sample,channel) affine,
