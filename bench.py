@@ -181,6 +181,8 @@ def main():
                     "the split-bf16 kernel in split / bf16 precision (library default: ops.SPLIT_3X3_MIN_COUT)")
     ap.add_argument("--no-couple-epilogue", action="store_true", help="(ablation, block types other than CAT) sub-networks write "
                     "[s | t] and a separate affine launch applies the coupling")
+    ap.add_argument("--no-virtual-cat", action="store_true", help="(ablation, block types other than CAT) materialise the input "
+                    "cat(half, condition) of every coupling sub-network instead of reading it from its two tensors")
     ap.add_argument("--group-layers", action="store_true", help="(ablation) the k-th residual layers of the five independent sub-networks "
                     "of a CAT step in one grouped launch instead of one launch per sub-network and layer (measured: no gain)")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
@@ -212,6 +214,8 @@ def main():
         ops.set_option("winograd_2d", a.wino2d)
     if a.no_couple_epilogue:
         ops.COUPLE_EPILOGUE = False
+    if a.no_virtual_cat:
+        ops.VIRTUAL_CAT = False
     if a.group_layers:
         ops.GROUP_LAYERS = True
     if a.split3x3_min is not None:

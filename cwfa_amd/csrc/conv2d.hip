@@ -153,8 +153,15 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
         }
     }
     const bool has_aff = PRO && p.o.in_scale != nullptr, has_add = PRO && p.o.in_add != nullptr;
-    const int xbytes = (int)((int64_t)p.Cin * HW * 4);
+    // two-source input (cwfa_conv_opts.in_cat: the channel concatenation of a coupling sub-network's input, never materialised):
+    // chunks [0, n1) come from x (its channels past in_cat_c1 are out of range = the zero columns the bank was packed with),
+    // chunks [n1, nchunks) from in_cat
+    const bool cat = !PRO && p.o.in_cat != nullptr;
+    const int n1 = cat ? p.o.in_cat_from / C::CK : p.nchunks;
+    const int xbytes = (int)((int64_t)(cat ? p.o.in_cat_c1 : p.Cin) * HW * 4);
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)t.b * p.x_bs), 0, xbytes, 0x00020000);
+    const auto rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cat ? p.o.in_cat + (int64_t)t.b * p.o.in_cat_bs : p.x), 0,
+                                                       cat ? (int)((int64_t)(p.Cin - p.o.in_cat_from) * HW * 4) : 0, 0x00020000);
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(has_add ? p.o.in_add + (int64_t)t.b * p.o.in_add_bs : p.x), 0, has_add ? xbytes : 0, 0x00020000);
     const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
@@ -176,7 +183,8 @@ __device__ __forceinline__ void conv_mainloop(const ConvParams& p, const Tile& t
     float sr[NP], hr[NP];
     f32x4 wr[C::WPT];
     auto load_x = [&](int i, int chunk) {
-        xr[i] = ldx(rx, voff[i], chunk * chunk_bytes);
+        if (chunk < n1) xr[i] = ldx(rx, voff[i], chunk * chunk_bytes);              // (uniform)
+        else xr[i] = ldx(rx2, voff[i], (chunk - n1) * chunk_bytes);
         if constexpr (PRO) {
             if (has_aff) {
                 sr[i] = ldf(rsc, cl4[i], chunk * C::CK * 4);
@@ -995,7 +1003,8 @@ extern "C" int cwfa_conv_split_pack_f32(const float* w, void* packed, int Cout, 
 
 extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                    int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
-    CWFA_REQUIRE(!(opts && (opts->in_blocked8 || opts->out_blocked8)), CWFA_E_INVAL, "cwfa_conv_split_f32: blocked layouts are not built here");
+    CWFA_REQUIRE(!(opts && (opts->in_blocked8 || opts->out_blocked8 || opts->in_cat)), CWFA_E_INVAL,
+                 "cwfa_conv_split_f32: blocked layouts / two-source inputs are not built here");
     CWFA_REQUIRE(ws && w_packed && y, CWFA_E_INVAL, "cwfa_conv_split_f32: null pointer");
     CWFA_REQUIRE(ks == 1, CWFA_E_SHAPE, "cwfa_conv_split_f32: kernel size %d (1x1 only; 3x3: cwfa_conv3x3_split_f32)", ks);
     SplitParams sp{};
@@ -1072,6 +1081,11 @@ extern "C" int cwfa_conv2d_pack_f32(const float* w, float* packed, int Cout, int
 extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,
                                int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
     CWFA_REQUIRE(!(opts && opts->in_blocked8), CWFA_E_INVAL, "cwfa_conv2d_f32: in_blocked8 is a cwfa_conv3x3_split_f32 feature");
+    CWFA_REQUIRE(!(opts && opts->in_cat) || (ks == 1 && Cout <= 64 && !opts->in_scale && !opts->in_add && opts->in_cat_from % 16 == 0 &&
+                                             opts->in_cat_from > 0 && opts->in_cat_from < Cin && opts->in_cat_c1 > 0 &&
+                                             opts->in_cat_c1 <= opts->in_cat_from),
+                 CWFA_E_INVAL, "cwfa_conv2d_f32: in_cat needs a 1x1 bank with <= 64 outputs packed with in_cat_from (a multiple of 16) "
+                               "columns for the first source, and no load-side affine / add");
     CWFA_REQUIRE(!(opts && opts->out_blocked8) || (ks == 1 && Cout % 8 == 0 && !opts->residual && opts->act == CWFA_ACT_NONE &&
                                                    opts->act2 == CWFA_ACT_NONE && !opts->upshuffle2 && !opts->in_scale && !opts->in_add &&
                                                    cwfa_aligned16(y) && (y_bs & 3) == 0 && (!opts->bias || cwfa_aligned16(opts->bias))),

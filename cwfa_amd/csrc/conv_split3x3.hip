@@ -608,7 +608,7 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     p.x = x; p.wp = w_packed; p.y = y;
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
     if (opts) p.o = *opts;
-    CWFA_REQUIRE(!p.o.upshuffle2, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: upshuffle2 is a 1x1 feature");
+    CWFA_REQUIRE(!p.o.upshuffle2 && !p.o.in_cat, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: upshuffle2 / in_cat are 1x1 features");
     CWFA_REQUIRE(!p.o.in_blocked8 || (Cin % 8 == 0 && cwfa_aligned16(x) && (x_bs & 3) == 0 && !p.o.in_add), CWFA_E_ALIGN,
                  "cwfa_conv3x3_split_f32: blocked input needs Cin %% 8 == 0, 16-byte alignment and no added tensor");
     CWFA_REQUIRE(!p.o.out_blocked8 || (Cout % 8 == 0 && cwfa_aligned16(y) && (y_bs & 3) == 0 && !p.o.residual && p.o.act2 == CWFA_ACT_NONE &&

@@ -136,12 +136,20 @@ class wavelet_flow_subnetwork(nn.Module):
         P = self._packed.get
         fused = self.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None
                                         for blk in (self.block2, self.block4, self.block6))
-        H_, W_ = u.shape[2], u.shape[3]
+        H_, W_ = (u[0] if isinstance(u, (list, tuple)) else u).shape[2:4]
         split_layers = fused and ops._split_bf16 >= 2 and 64 * H_ * W_ * 4 < 2 ** 31
-        pc_in = P(conv_in)
+        # ``u`` may be the list [half, condition] of a coupling block's input: the 1x1 then reads cat(half, condition) from the
+        # two tensors (ops.pack_conv_weight_cat) instead of a materialised concatenation (coupling_layers.py:74-87)
+        two = isinstance(u, (list, tuple))
+        if two and not (len(u) == 2 and ops.VIRTUAL_CAT and conv_in.kernel_size == (1, 1) and conv_in.out_channels <= 64):
+            u, two = ops.concat_channels(list(u)), False
+        pc_in = self._cat_bank(conv_in, u[0].shape[1]) if two else P(conv_in)
         # the first map is channel-blocked already when the 1x1 kernel that writes it can do so (see below)
         blocked = bool(split_layers and ops.BLOCKED_MAPS and not pc_in.split and pc_in.ks == 1 and pc_in.cout == 64)
-        b = ops.conv2d(u, pc_in, bias=conv_in.bias, out_blocked=blocked)
+        if two:
+            b = ops.conv2d(u[0], pc_in, bias=conv_in.bias, out_blocked=blocked, cat=u[1])
+        else:
+            b = ops.conv2d(u, pc_in, bias=conv_in.bias, out_blocked=blocked)
         # the maps between the layers are private to this stack: on the split-bf16 kernels they are kept CHANNEL-BLOCKED
         # ([8][H][W][8]: 16-byte accesses in the layer kernel, see cwfa_subnet_layer_split_f32) whenever their consumer reads
         # that layout -- the next layer, and the last convolution if it runs on the split-bf16 3x3 kernel
@@ -163,6 +171,13 @@ class wavelet_flow_subnetwork(nn.Module):
             return ops.conv3x3_couple(b, self._couple_bank(conv_out), *couple, in_blocked=blocked)
         return ops.conv2d(b, pc_out, bias=conv_out.bias, out=out, in_blocked=blocked)
 
+    def _cat_bank(self, conv, c1):
+        w = conv.weight
+        pc = self._panels.get(("cat", id(conv), c1))
+        if pc is None or pc.version != w._version or pc.src_ptr != w.data_ptr() or pc.epoch != ops.pack_epoch():
+            pc = self._panels[("cat", id(conv), c1)] = ops.pack_conv_weight_cat(w, c1)
+        return pc
+
     def _couple_bank(self, conv):
         w, bias = conv.weight, conv.bias
         hit = self._panels.get(("c", id(conv)))
@@ -183,7 +198,7 @@ class wavelet_flow_subnetwork(nn.Module):
         if (not self.normal or not ops.couple_fused() or self.conv_type is not nn.Conv2d or self.c_out != 2 * n or n > 64
                 or clamp_kind is None or (max(self.n_ch, n) + 64) * x.shape[2] * x.shape[3] * 4 >= 2 ** 31):
             return False
-        u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+        u = parts[0] if len(parts) == 1 else list(parts)
         self._stack(u, self.block12, self.block72[1], couple=(x, out, clamp_kind, clamp, pre_scale, rev, logdet))
         return True
 
@@ -205,7 +220,7 @@ class wavelet_flow_subnetwork(nn.Module):
     def affine_parts(self, parts, n_s):
         """(s_raw, t, t_neg_div_sqrt2) for a coupling block, without materialising any concatenation."""
         if self.normal:
-            u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+            u = parts[0] if len(parts) == 1 else list(parts)
             a = self._stack(u, self.block12, self.block72[1])
             return a[:, :n_s], a[:, n_s:], False
         n = self.c_in // 2

@@ -331,7 +331,8 @@ def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=Non
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
-    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch", "version1", "src_ptr1")
+    __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch", "version1", "src_ptr1", "cat_c1",
+                 "cat_from")
 
     def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
@@ -369,17 +370,42 @@ def pack_conv_weight(w, transposed=False):
     return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr())
 
 
+def pack_conv_weight_cat(w, c1):
+    """1x1 bank [Cout <= 64, c1 + c2, 1, 1] for conv2d(x, pc, cat=x2): the input cat(x, x2) is read from its two tensors.  The
+    columns of the first source are padded with zeros to a multiple of 16 (one K chunk of the kernel)."""
+    w = _dev(w, "weight").detach()
+    cout, cin, ks, kw = w.shape
+    if ks != 1 or kw != 1 or cout > 64 or not (0 < c1 < cin):
+        raise ValueError(f"pack_conv_weight_cat: a 1x1 bank with <= 64 outputs and 0 < c1 < Cin is needed, got {tuple(w.shape)}, c1 = {c1}")
+    start = (c1 + 15) // 16 * 16
+    wz = torch.zeros((cout, start + cin - c1, 1, 1), dtype=torch.float32, device=w.device)
+    wz[:, :c1] = w[:, :c1]
+    wz[:, start:] = w[:, c1:]
+    pc = pack_conv_weight(wz)                       # (cout <= 64: always the direct kernel's layout)
+    pc.version, pc.src_ptr = w._version, w.data_ptr()
+    pc.cat_c1, pc.cat_from = c1, start
+    return pc
+
+
 def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=None, in_scale=None, in_shift=None,
-           in_add=None, out=None, in_blocked=False, out_blocked=False):
+           in_add=None, out=None, in_blocked=False, out_blocked=False, cat=None):
     """y = act2(act(conv(x') + bias) + residual), x' = x*in_scale[c] + in_shift[c] + in_add.  Transposed banks
     (ConvTranspose2d k2 s2) write the pixel-shuffled [B,Co,2H,2W] output."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cin, H, W = x.shape
-    if Cin != pc.cin:
-        raise ValueError(f"conv2d: input has {Cin} channels, filter bank expects {pc.cin}")
     o = ConvOpts()
     keep = [x]
+    if cat is not None:                     # the input is cat(x, cat) read from its two tensors (pack_conv_weight_cat)
+        cat, cbs = planes(cat, "cat")
+        c1 = getattr(pc, "cat_c1", None)
+        if c1 is None or Cin != c1 or tuple(cat.shape) != (B, pc.cin - pc.cat_from, H, W) or in_scale is not None or in_add is not None:
+            raise ValueError("conv2d: `cat` needs a bank from pack_conv_weight_cat for exactly these two inputs, and no load-side prologue")
+        o.in_cat, o.in_cat_bs, o.in_cat_from, o.in_cat_c1 = cat.data_ptr(), cbs, pc.cat_from, c1
+        keep.append(cat)
+        Cin = pc.cin
+    if Cin != pc.cin:
+        raise ValueError(f"conv2d: input has {Cin} channels, filter bank expects {pc.cin}")
     up = bool(pc.transposed)
     oshape = (B, pc.cout // 4, 2 * H, 2 * W) if up else (B, pc.cout, H, W)
     if out is None:
@@ -521,6 +547,7 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
 
 BLOCKED_MAPS = True          # (tuning / ablation) False: the maps between the split-bf16 sub-network layers stay NCHW
 BLOCKED_UNET = False         # the same for the map between the two convolutions of a UNetConvBlock: built and tested, no gain (unet.py)
+VIRTUAL_CAT = True           # (tuning / ablation) False: the input cat(half, condition) of a coupling sub-network is materialised
 COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
 
 

@@ -202,6 +202,13 @@ typedef struct {
                                  feeding cwfa_subnet_layer_split_f32 with layout bit 0); cwfa_conv3x3_split_f32
                                  with a bias / PReLU epilogue (the first convolution of a UNetConvBlock; its
                                  statistics: cwfa_channel_stats_blocked8_f32, its consumer: in_blocked8)       */
+    const float* in_cat;      /* cwfa_conv2d_f32, 1x1 banks with <= 64 outputs, no other in_*: the input is the channel
+                                 concatenation cat(x, in_cat) WITHOUT materialising it (the input of a coupling
+                                 sub-network, cat(half, *conditions): coupling_layers.py:74-87, all_in_one_block.py:
+                                 244-247).  x holds in_cat_c1 channels; the bank is packed for Cin = in_cat_from +
+                                 channels(in_cat) with zero columns in [in_cat_c1, in_cat_from), in_cat_from % 16 == 0 */
+    int64_t in_cat_bs;
+    int in_cat_from, in_cat_c1;
 } cwfa_conv_opts;
 
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,

@@ -1235,6 +1235,26 @@ def test_maxpool_with_affine_vs_torch(shape):
     assert torch.equal(y2.cpu(), torch.nn.functional.adaptive_max_pool2d(x, (Ho, Wo)))
 
 
+@pytest.mark.parametrize("cfg", [(2, 3, 5, 9, 31, 8), (1, 24, 48, 40, 64, 64), (1, 16, 6, 17, 20, 64), (2, 7, 29, 16, 36, 40)])
+def test_conv1x1_two_source_input_equals_the_concatenation(cfg):
+    """cwfa_conv_opts.in_cat: the 1x1 convolution over cat(x, x2) read from the two tensors (the input of a coupling
+    sub-network, coupling_layers.py:74-87) == the same convolution over the materialised concatenation, bit for bit (the zero
+    columns the bank is padded with add +0.0 in place), both staging forms (W % 4 == 0 or not), channel-sliced views."""
+    from cwfa_amd import ops
+    B, c1, c2, H, W, cout = cfg
+    g = torch.Generator().manual_seed(c1 + c2)
+    w = (torch.randn(cout, c1 + c2, 1, 1, generator=g) / (c1 + c2) ** 0.5).cuda()
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    big = torch.randn(B, c1 + 3, H, W, generator=g).cuda()
+    x, x2 = big[:, 3:], torch.randn(B, c2, H, W, generator=g).cuda()
+    ref = ops.conv2d(ops.concat_channels([x, x2]), ops.pack_conv_weight(w), bias=bias)
+    pc = ops.pack_conv_weight_cat(w, c1)
+    assert torch.equal(ops.conv2d(x, pc, bias=bias, cat=x2), ref)
+    assert_close(ref, torch.nn.functional.conv2d(torch.cat([x, x2], 1).double().cpu(), w.double().cpu(), bias.double().cpu()), 2e-6)
+    with pytest.raises(ValueError):
+        ops.conv2d(x2, pc, bias=bias, cat=x)
+
+
 def _to_blocked(t):
     B, Cc, H, W = t.shape
     return t.view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, Cc, H, W)
