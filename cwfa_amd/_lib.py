@@ -104,6 +104,9 @@ SIGNATURES = {
     "cwfa_conv3x3_split_packed_bytes": (i64, [i, i]),
     "cwfa_conv3x3_split_pack_f32": (i, [p, p, i, i, p]),
     "cwfa_conv3x3_split_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
+    "cwfa_conv7x7_split_packed_bytes": (i64, [i, i]),
+    "cwfa_conv7x7_split_pack_f32": (i, [p, p, i, i, p]),
+    "cwfa_conv7x7_split_f32": (i, [p, p, p, i, i, i, i, i, i64, i64, C.POINTER(ConvOpts), p]),
     "cwfa_couple_rows": (i, [i, p]),
     "cwfa_conv3x3_split_couple_f32": (i, [p, p, p, i, i, i, i, i64, C.POINTER(Couple), p]),
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),

@@ -31,18 +31,29 @@ extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 
 
 namespace {
 
-constexpr int TR = 8, TC = 32, XR = TR + 2, XC = TC + 2, NT = TR;          // NT: n-tiles per wave (4 rows x 2 halves)
-constexpr int EPK = XR * XC;                // 306 entries per k half
-constexpr int KHB = 5440;                   // bytes of one k-half plane: 306 x 16 = 4896 padded to a multiple of 256 (bank phase)
-constexpr int XPB = 2 * KHB;                // one piece plane
-constexpr int XB = 3 * XPB;                 // one input buffer (30 720)
-static_assert(EPK * 16 <= KHB && EPK > 256 && EPK <= 384, "staging entry map");
+constexpr int TR = 8, TC = 32, NT = TR;     // NT: n-tiles per wave (4 rows x 2 halves)
 
-template <int MPW>
+// input-tile geometry of a KS x KS convolution (KS = 3: the form everything above describes; KS = 7: the ConvNeXt convolution of
+// the LRNN, networks.py:488 -- the same kernel with a 3-pixel halo, 49 taps and a 49-step period over two 16-channel chunks)
+template <int KS>
+struct XG {
+    static constexpr int PAD = KS / 2, XR = TR + 2 * PAD, XC = TC + 2 * PAD, NTAP = KS * KS;
+    static constexpr int EPK = XR * XC;                 // entries per k half: 306 (3x3), 532 (7x7)
+    // bytes of one k-half plane: EPK x 16 padded so that the two k halves differ by 64 bytes modulo 256 (bank phase):
+    // 3x3: 4896 -> 5440;  7x7: 8512 already is
+    static constexpr int KHB = KS == 3 ? 5440 : 8512;
+    static constexpr int XPB = 2 * KHB;                 // one piece plane
+    static constexpr int XB = 3 * XPB;                  // one input buffer (3x3: 30 720; 7x7: 51 072)
+    static constexpr int NEK = KS == 3 ? 2 : 3;         // staging entries per thread and chunk
+    static_assert(EPK * 16 <= KHB && KHB % 256 == 64 && 2 * EPK <= 512 * NEK, "staging entry map");
+    static_assert(KS != 3 || (EPK > 256 && EPK <= 384), "3x3 staging entry map");
+};
+
+template <int MPW, int KS = 3>
 struct Geo {
     static constexpr int CT = 64 * MPW;                 // output channels per block
     static constexpr int WSL = 3 * 4 * CT * 16;         // bytes of one weight slice (K = 32)
-    static constexpr int LDS = 2 * XB + 2 * WSL;        // MPW = 4: 159 744
+    static constexpr int LDS = 2 * XG<KS>::XB + 2 * WSL;    // 3x3, MPW = 4: 159 744;  7x7, MPW = 1: 126 720
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -93,7 +104,8 @@ __device__ __forceinline__ float act_of(float v, float alpha) {
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // byte offset of the B fragments of tap t in buffer `buf`, relative to the lane base
-__host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XB + ((tap / 3) * XC + tap % 3) * 16; }
+template <int KS>
+__host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XG<KS>::XB + ((tap / KS) * XG<KS>::XC + tap % KS) * 16; }
 
 enum { EPI_RUNTIME = -1, EPI_COUPLE = -2 };
 
@@ -109,8 +121,11 @@ __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
 
 // ADD: a second tensor is added on load (UNet skip); ACT1: compile-time activation of the common epilogues (bias -> ACT1),
 // EPI_RUNTIME = whatever cwfa_conv_opts says (bias -> act -> + residual -> act2)
-template <int MPW, bool SIX, bool ADD, int ACT1>
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
+    typedef XG<KS> G;
+    constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD;
+    static_assert(KS == 3 || (MPW == 1 && !ADD), "7x7: the 64-channel tiling without a skip add");
     constexpr int CT = 64 * MPW;                        // output channels per block
     constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -128,21 +143,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 
     // ---- staging entries (two per thread): k = 0: k half wave >> 2, entries 0..255; k = 1: entries 256..339 of k half
     // (wave >> 1) & 1 for waves 0..3 (so that the k half, hence the channel, is uniform over a wave)
-    constexpr int NEK = 2;
+    // (7x7: three per thread, entry e = tid + 512 k of the 2 x 532; the k half is NOT uniform over a wave there, so it rides in the
+    // per-lane offset and the form has no load-side affine)
+    constexpr int NEK = G::NEK;
     int ekh[NEK], eidx[NEK];
     bool fin[NEK];
     unsigned fo[NEK];
-    ekh[0] = wave >> 2; eidx[0] = tid & 255; fin[0] = true;
-    ekh[1] = (wave >> 1) & 1; eidx[1] = 256 + (tid & 127); fin[1] = wave < 4 && eidx[1] < EPK;
+    if constexpr (KS == 3) {
+        ekh[0] = wave >> 2; eidx[0] = tid & 255; fin[0] = true;
+        ekh[1] = (wave >> 1) & 1; eidx[1] = 256 + (tid & 127); fin[1] = wave < 4 && eidx[1] < EPK;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NEK; ++k) {
+            const int e = tid + 512 * k;
+            ekh[k] = e >= EPK;
+            eidx[k] = e - ekh[k] * EPK;
+            fin[k] = e < 2 * EPK;
+        }
+    }
     bool fok[NEK];
 #pragma unroll
     for (int k = 0; k < NEK; ++k) {
         const int r = eidx[k] / XC, c = eidx[k] % XC;
-        const int gr = row0 + r - 1, gc = col0 + c - 1;
+        const int gr = row0 + r - PAD, gc = col0 + c - PAD;
         fok[k] = fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
         // blocked input ([Cin/8][H][W][8], cwfa_conv_opts.in_blocked8): the 32-byte entry of the pixel; its channel block rides
         // in the scalar offset
         fo[k] = !fok[k] ? OOB : p.o.in_blocked8 ? (unsigned)((gr * p.W + gc) * 32) : (unsigned)((gr * p.W + gc) * 4);
+        if constexpr (KS != 3) fo[k] = !fok[k] ? OOB : fo[k] + (unsigned)(ekh[k] * 8) * (unsigned)plane;
     }
     const int xbytes = p.Cin * plane;                   // channels >= Cin: out of range, 0.0
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)b * p.x_bs), 0, xbytes, 0x00020000);
@@ -158,8 +186,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 
     auto load_entry = [&](auto kc, float (&xv)[8], float (&av)[8], int chunk) {
         constexpr int k = decltype(kc)::value;
-        const int ch0 = chunk * 16 + ekh[k] * 8;
-        if (!ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each (the
+        const int ch0 = chunk * 16 + (KS == 3 ? ekh[k] * 8 : 0);        // (7x7: the k half is in the lane's offset)
+        if (KS == 3 && !ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each (the
                                                         // load-side affine is per channel: unchanged)
             const f32x4 lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane, 0));
             const f32x4 hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane + 16, 0));
@@ -179,8 +207,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     };
     auto store_entry = [&](auto kc, const float (&xv)[8], const float (&av)[8], int chunk, int buf) {
         constexpr int k = decltype(kc)::value;
-        if (k == 1 && !fin[1]) return;
-        const int ch0 = chunk * 16 + ekh[k] * 8;          // wave-uniform: the affine tables are read through scalar loads
+        if (KS == 3 && k == 1 && !fin[1]) return;
+        const int ch0 = chunk * 16 + ekh[k] * 8;          // wave-uniform (3x3): the affine tables are read through scalar loads
         bf16x8 pc[3];
         float scv[8], shv[8];
         if (has_aff) {
@@ -201,8 +229,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
             pc[0][j] = a1; pc[1][j] = a2; pc[2][j] = a3;
         }
         char* dst = lds + buf * XB + ekh[k] * KHB + eidx[k] * 16;
+        if (KS == 3 || fin[k]) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
+            for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
+        }
     };
 
     // ---- weight slices by LDS-DMA: WSL / 1024 wave instructions per slice, a quarter per wave
@@ -264,24 +294,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    read_b(0, blane + (sel ? tap_off(0, 1) : tap_off(0, 0)), 0);          // step 0: taps 0 | 1 of chunk 0
+    read_b(0, blane + (sel ? tap_off<KS>(0, 1) : tap_off<KS>(0, 0)), 0);  // step 0: taps 0 | 1 of chunk 0
     // ONE step as the body of a rolled loop (the accumulators are loop-carried values: unrolling the nine steps of a period
     // makes the register allocator split their live ranges and keep copies); P = position in the 9-step period
     int sl = 0, P = 0, ce = 0;                           // ring slot of this step's slice; period position; even chunk of the period
     for (int step = 0; step < p.nsteps; ++step) {
         const int co = ce + 1;                            // odd chunk (past the end: all zeros, costs only time)
         // units of this step: even chunk taps (2P, 2P+1) for P < 4; (tap 8 | odd tap 0) at P = 4; odd taps (2P-9, 2P-8) after
+        // (7x7: 49 taps, the same pairing with a 49-step period)
         const int uA = 2 * P, uB = 2 * P + 1;
-        const int bufA = uA >= 9, tA = uA - 9 * bufA, bufB = uB >= 9, tB = uB - 9 * bufB;
-        const int offA = bufA * XB + ((tA / 3) * XC + tA % 3) * 16, offB = bufB * XB + ((tB / 3) * XC + tB % 3) * 16;
+        const int bufA = uA >= NTAP, tA = uA - NTAP * bufA, bufB = uB >= NTAP, tB = uB - NTAP * bufB;
+        const int offA = bufA * XB + ((tA / KS) * XC + tA % KS) * 16, offB = bufB * XB + ((tB / KS) * XC + tB % KS) * 16;
+        // staging schedule inside a period: the odd buffer is free from step 0 (stores SB + k of the entries loaded in the period
+        // before), the even one right after the step that pairs tap NTAP-1 with the odd chunk's tap 0 (stores SA + k, loads LA + k
+        // a few steps earlier); the odd chunk after next is loaded at LB + k
+        constexpr int SB = 0, SA = KS == 3 ? 5 : 26, LA = KS == 3 ? 2 : 22, LB = KS == 3 ? 6 : 44;
         // -- order matters: in this rolled loop the compiler cannot count the vector-memory operations between a staging load
         // and its use, so it waits for ALL of them (vmcnt(0)) before the split below: that must come BEFORE this step issues
         // its own DMA and loads, when everything older has long landed (after them it cost 2 - 9 thousand cycles per step).
         // the vector-heavy part of staging: split + LDS stores of one entry of the chunk after next
-        if (P == 0) store_entry(ic<0>{}, xb[0], ab[0], co, 1);
-        if (P == 1) store_entry(ic<1>{}, xb[1], ab[1], co, 1);
-        if (P == 5) store_entry(ic<0>{}, xa[0], aa[0], ce + 2, 0);
-        if (P == 6) store_entry(ic<1>{}, xa[1], aa[1], ce + 2, 0);
+        // (written out per entry: behind a generic lambda the staged-entry arrays stopped being promoted to registers)
+        if (P == SB) store_entry(ic<0>{}, xb[0], ab[0], co, 1);
+        if (P == SB + 1) store_entry(ic<1>{}, xb[1], ab[1], co, 1);
+        if constexpr (NEK > 2) {
+            if (P == SB + 2) store_entry(ic<NEK - 1>{}, xb[NEK - 1], ab[NEK - 1], co, 1);
+        }
+        if (P == SA) store_entry(ic<0>{}, xa[0], aa[0], ce + 2, 0);
+        if (P == SA + 1) store_entry(ic<1>{}, xa[1], aa[1], ce + 2, 0);
+        if constexpr (NEK > 2) {
+            if (P == SA + 2) store_entry(ic<NEK - 1>{}, xa[NEK - 1], aa[NEK - 1], ce + 2, 0);
+        }
         FENCE();
         // first A fragments (the step's first B fragments were requested before the barrier of the step before)
         const int abase = alane + sl * WSL;
@@ -310,10 +352,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                 // the DMA: they overwrite loop-carried registers, so the compiler waits for every older vector-memory
                 // operation first -- which must not include a DMA issued a moment ago.
                 if (m0 == 0 && nt == 0) {
-                    if (P == 2) load_entry(ic<0>{}, xa[0], aa[0], ce + 2);
-                    if (P == 3) load_entry(ic<1>{}, xa[1], aa[1], ce + 2);
-                    if (P == 6) load_entry(ic<0>{}, xb[0], ab[0], co + 2);
-                    if (P == 7) load_entry(ic<1>{}, xb[1], ab[1], co + 2);
+                    if (P == LA) load_entry(ic<0>{}, xa[0], aa[0], ce + 2);
+                    if (P == LA + 1) load_entry(ic<1>{}, xa[1], aa[1], ce + 2);
+                    if constexpr (NEK > 2) {
+                        if (P == LA + 2) load_entry(ic<NEK - 1>{}, xa[NEK - 1], aa[NEK - 1], ce + 2);
+                    }
+                    if (P == LB) load_entry(ic<0>{}, xb[0], ab[0], co + 2);
+                    if (P == LB + 1) load_entry(ic<1>{}, xb[1], ab[1], co + 2);
+                    if constexpr (NEK > 2) {
+                        if (P == LB + 2) load_entry(ic<NEK - 1>{}, xb[NEK - 1], ab[NEK - 1], co + 2);
+                    }
                     FENCE();
                 }
                 if (m0 == 0 && nt == 1) {
@@ -324,10 +372,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         }
         // first B fragments of the next step: the input tiles it reads were completed at least two barriers ago
         {
-            const int nP = P == 8 ? 0 : P + 1;
+            const int nP = P == NTAP - 1 ? 0 : P + 1;
             const int nA = 2 * nP, nB = 2 * nP + 1;
-            const int nbufA = nA >= 9, ntA = nA - 9 * nbufA, nbufB = nB >= 9, ntB = nB - 9 * nbufB;
-            const int noffA = nbufA * XB + ((ntA / 3) * XC + ntA % 3) * 16, noffB = nbufB * XB + ((ntB / 3) * XC + ntB % 3) * 16;
+            const int nbufA = nA >= NTAP, ntA = nA - NTAP * nbufA, nbufB = nB >= NTAP, ntB = nB - NTAP * nbufB;
+            const int noffA = nbufA * XB + ((ntA / KS) * XC + ntA % KS) * 16, noffB = nbufB * XB + ((ntB / KS) * XC + ntB % KS) * 16;
             read_b(0, blane + (sel ? noffB : noffA), 0);
             FENCE();
         }
@@ -338,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         else asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         sl ^= 1;
-        if (++P == 9) {
+        if (++P == NTAP) {
             P = 0;
             ce += 2;
         }
@@ -458,17 +506,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 // (chunk u / 9, tap u % 9), k half g & 1: element j = w[co][chunk*16 + (g&1)*8 + j][tap] (0 beyond Cout / Cin / the last unit)
 template <int CT>
 __global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin,
-                                                            int nchunks, int nsteps, int64_t total) {
+                                                            int nchunks, int nsteps, int64_t total, int ntap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over [ctile][step][g 4][co CT]
     if (i >= total) return;
     const int col = (int)(i % CT), g = (int)((i / CT) % 4), s = (int)((i / (4 * CT)) % nsteps), ctile = (int)(i / ((int64_t)4 * CT * nsteps));
-    const int u = 2 * s + (g >> 1), chunk = u / 9, tap = u % 9, co = ctile * CT + col;
+    const int u = 2 * s + (g >> 1), chunk = u / ntap, tap = u % ntap, co = ctile * CT + col;
     unsigned short pc[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = chunk * 16 + (g & 1) * 8 + j;
         float v = 0.f;
-        if (co < Cout && ci < Cin && chunk < nchunks) v = w[((int64_t)co * Cin + ci) * 9 + tap];
+        if (co < Cout && ci < Cin && chunk < nchunks) v = w[((int64_t)co * Cin + ci) * ntap + tap];
         __bf16 a1, a2, a3;
         split3<true>(v, a1, a2, a3);
         pc[0][j] = __builtin_bit_cast(unsigned short, a1);
@@ -487,12 +535,12 @@ __global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restr
 }
 
 inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 64 ? 2 : 1; }
-inline int nsteps_of(int Cin) { return 9 * (((Cin + 15) / 16 + 1) / 2); }      // whole 9-step periods of two 16-channel chunks
+inline int nsteps_of(int Cin, int ntap = 9) { return ntap * (((Cin + 15) / 16 + 1) / 2); }   // whole periods of two 16-channel chunks
 
-template <int MPW, bool SIX, bool ADD, int ACT1>
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3>
 int launch(const SParams& p, hipStream_t stream) {
-    typedef Geo<MPW> G;
-    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1>;
+    typedef Geo<MPW, KS> G;
+    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -591,9 +639,9 @@ extern "C" int cwfa_conv3x3_split_pack_f32(const float* w, void* packed, int Cou
     const int64_t total = (int64_t)((Cout + ct - 1) / ct) * nsteps * 4 * ct;
     const dim3 grid((unsigned)((total + 255) / 256));
     uint4* out = reinterpret_cast<uint4*>(packed);
-    if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
-    else if (mpw == 2) hipLaunchKernelGGL(split3x3_pack_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
-    else hipLaunchKernelGGL(split3x3_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total);
+    if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else if (mpw == 2) hipLaunchKernelGGL(split3x3_pack_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else hipLaunchKernelGGL(split3x3_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     CWFA_LAUNCH_CHECK("cwfa_conv3x3_split_pack_f32");
     return CWFA_OK;
 }
@@ -632,4 +680,45 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
     if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
     return six ? launch_epi<1, true>(p, st) : launch_epi<1, false>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------ 7x7 (ConvNeXt, networks.py:488)
+extern "C" int64_t cwfa_conv7x7_split_packed_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cout > 64 || Cin <= 0) return -1;
+    return (int64_t)nsteps_of(Cin, 49) * 3 * 4 * 64 * 16;
+}
+
+extern "C" int cwfa_conv7x7_split_pack_f32(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv7x7_split_pack_f32: null pointer");
+    CWFA_REQUIRE(Cout > 0 && Cout <= 64 && Cin > 0, CWFA_E_SHAPE, "cwfa_conv7x7_split_pack_f32: 1 <= Cout <= 64");
+    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv7x7_split_pack_f32: packed image must be 16-byte aligned");
+    const int nchunks = (Cin + 15) / 16, nsteps = nsteps_of(Cin, 49);
+    const int64_t total = (int64_t)nsteps * 4 * 64;
+    hipLaunchKernelGGL(split3x3_pack_kernel<64>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<uint4*>(packed), Cout, Cin, nchunks, nsteps, total, 49);
+    CWFA_LAUNCH_CHECK("cwfa_conv7x7_split_pack_f32");
+    return CWFA_OK;
+}
+
+extern "C" int cwfa_conv7x7_split_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                                      int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream) {
+    CWFA_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Cout <= 64 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_conv7x7_split_f32: bad size (Cout <= 64)");
+    if (B == 0 || H == 0 || W == 0) return CWFA_OK;
+    CWFA_REQUIRE(x && w_packed && y, CWFA_E_INVAL, "cwfa_conv7x7_split_f32: null pointer");
+    CWFA_REQUIRE(cwfa_aligned16(w_packed), CWFA_E_ALIGN, "cwfa_conv7x7_split_f32: packed weights must be 16-byte aligned");
+    SParams p{};
+    p.x = x; p.wp = w_packed; p.y = y;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
+    if (opts) p.o = *opts;
+    CWFA_REQUIRE(!p.o.upshuffle2 && !p.o.in_cat && !p.o.in_scale && !p.o.in_add && !p.o.in_blocked8 && !p.o.out_blocked8 && !p.o.residual &&
+                     p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE,
+                 CWFA_E_INVAL, "cwfa_conv7x7_split_f32: bias-only epilogue, no load-side prologue, NCHW maps");
+    p.nchunks = (Cin + 15) / 16;
+    p.nsteps = nsteps_of(Cin, 49);
+    p.tiles_x = (W + TC - 1) / TC;
+    CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(Cout + 64) * H * W * 4 < (1ll << 31), CWFA_E_SHAPE,
+                 "cwfa_conv7x7_split_f32: one sample's input / output must stay below 2 GiB");
+    CWFA_REQUIRE((int64_t)p.tiles_x * ((H + TR - 1) / TR) < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_conv7x7_split_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    return g_cwfa_split_products != 1 ? launch<1, true, false, CWFA_ACT_NONE, 7>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 7>(p, st);
 }

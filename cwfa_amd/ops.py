@@ -362,6 +362,10 @@ def pack_conv_weight(w, transposed=False):
         packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv3x3_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv3x3_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
+    if SPLIT_7X7 and _split_bf16 >= 2 and ks == 7 and cout <= 64 and cin >= 32:   # the ConvNeXt convolution of the LRNN (64 -> 64)
+        packed = torch.empty(L.cwfa_conv7x7_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+        check(L.cwfa_conv7x7_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv7x7_split_pack")
+        return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
     n = L.cwfa_conv2d_packed_floats(cout, cin, ks)
     if n <= 0:
         raise ValueError(f"unsupported filter bank {tuple(w.shape)}")
@@ -463,7 +467,13 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-    if pc.split and pc.ks == 3:
+    if pc.split and pc.ks == 7:
+        # the same kernel with a 3-pixel halo and 49 taps (bias-only epilogue, no prologue: what the ConvNeXt block needs)
+        if act or act2 or residual is not None or in_scale is not None or in_add is not None:
+            raise ValueError("conv2d: the split-bf16 7x7 kernel has a bias-only epilogue and no load-side prologue")
+        check(L.cwfa_conv7x7_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o), _stream()),
+              "conv7x7_split")
+    elif pc.split and pc.ks == 3:
         # fp32-accurate conv on the bf16 pipe, the kernel splits x on the way into LDS (prologue included)
         check(L.cwfa_conv3x3_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o),
                                        _stream()), "conv3x3_split")
@@ -547,6 +557,7 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
 
 BLOCKED_MAPS = True          # (tuning / ablation) False: the maps between the split-bf16 sub-network layers stay NCHW
 BLOCKED_UNET = False         # the same for the map between the two convolutions of a UNetConvBlock: built and tested, no gain (unet.py)
+SPLIT_7X7 = True             # (tuning / ablation) False: 7x7 convolutions stay on the fp32 MFMA kernel in split / bf16 precision
 VIRTUAL_CAT = True           # (tuning / ablation) False: the input cat(half, condition) of a coupling sub-network is materialised
 COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
 

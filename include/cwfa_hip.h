@@ -298,6 +298,12 @@ int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, float* y, int B
                            int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
 int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks, int64_t y_bs,
                            const cwfa_conv_opts* opts, void* stream);
+/* 7x7 (stride 1, zero padding 3; nn.Conv2d(C, C, 7, 1, 3) of the ConvNeXt block, networks.py:488) in the same arithmetic on the same
+ * kernel: 3-pixel halo, 49 taps, a 49-step period over two 16-channel chunks.  Cout <= 64; epilogue: bias only; no in_* prologue. */
+int64_t cwfa_conv7x7_split_packed_bytes(int Cout, int Cin);
+int cwfa_conv7x7_split_pack_f32(const float* w, void* packed, int Cout, int Cin, void* stream);
+int cwfa_conv7x7_split_f32(const float* x, const void* w_packed, float* y, int B, int Cin, int H, int W, int Cout,
+                           int64_t x_bs, int64_t y_bs, const cwfa_conv_opts* opts, void* stream);
 
 /* The LAST convolution of a coupling sub-network (3x3, 64 -> 2n channels: [s_raw | t], networks.py:633-638) with the affine
  * coupling applied from its accumulators -- s and t never reach memory:

@@ -1255,6 +1255,31 @@ def test_conv1x1_two_source_input_equals_the_concatenation(cfg):
         ops.conv2d(x2, pc, bias=bias, cat=x)
 
 
+@pytest.mark.parametrize("cfg", [(1, 64, 64, 40, 70), (2, 40, 33, 19, 33), (1, 64, 64, 128, 128), (1, 32, 64, 8, 32)])
+def test_split_bf16_7x7_is_fp32_accurate(cfg):
+    """cwfa_conv7x7_split_f32 (the split 3x3 kernel with a 3-pixel halo and 49 taps: the ConvNeXt convolution, networks.py:488)
+    against fp64 torch at the fp32 kernels' bound, ragged tiles, odd channel counts, batch > 1; and against the fp32 MFMA kernel."""
+    from cwfa_amd import ops
+    B, cin, cout, H, W = cfg
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 7, 7, generator=g) / (7 * cin ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=3)
+    y32 = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), bias=bias.cuda())
+    ops.set_precision("split_bf16")
+    try:
+        pc = ops.pack_conv_weight(w.cuda())
+        assert pc.split and pc.ks == 7
+        y = ops.conv2d(x.cuda(), pc, bias=bias.cuda())
+        with pytest.raises(ValueError):
+            ops.conv2d(x.cuda(), pc, bias=bias.cuda(), act="elu")
+    finally:
+        ops.set_precision("fp32")
+    assert_close(y, ref, 3e-6, "split 7x7 vs fp64")
+    assert_close(y, y32, 5e-6, "split 7x7 vs fp32 MFMA kernel")
+
+
 def _to_blocked(t):
     B, Cc, H, W = t.shape
     return t.view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, Cc, H, W)
