@@ -52,14 +52,16 @@ def family(key):
     if ks == "L":
         return "split_layer_kernel" if tag.endswith("+split") else "wino_layer_kernel"
     if tag.endswith("+split") and ks == 3:
-        # exactly the rocprofv3 name: conv3x3_split_kernel<MPW, SIX, ADD, ACT1> (csrc/conv_split3x3.hip: launch_epi)
+        # exactly the rocprofv3 name: conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS> (csrc/conv_split3x3.hip: launch_epi)
         pro, act, res, act2, _ = tag.split("|")
         plain = not res and not act2
         act1 = 2 if (plain and act == "prelu") else 0 if (plain and not act and not key[7]) else -1
         if tag.endswith("couple+split"):
             act1 = -2
-        return "conv3x3_split_kernel<%d, %s, %s, %d>" % (4 if cout > 128 else 2 if cout > 64 else 1, "true" if SPLIT_SIX else "false",
-                                                          "true" if key[7] else "false", act1)
+        return "conv3x3_split_kernel<%d, %s, %s, %d, 3>" % (4 if cout > 128 else 2 if cout > 64 else 1, "true" if SPLIT_SIX else "false",
+                                                             "true" if key[7] else "false", act1)
+    if tag.endswith("+split") and ks == 7:
+        return "conv3x3_split_kernel<1, %s, false, 0, 7>" % ("true" if SPLIT_SIX else "false")
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
@@ -72,9 +74,9 @@ def family(key):
 # kernel family (see family()) -> substrings of the rocprofv3 kernel names it covers (tools/pmc_traffic.py averages FETCH_SIZE /
 # WRITE_SIZE over the launches of all of them; the layer kernel has one instantiation per map layout)
 ROCPROF_NAMES = {
-    "conv3x3_split_kernel<4, true, false, 2>": ["conv3x3_split_kernel<4, true, false, 2>"],
-    "conv3x3_split_kernel<4, true, true, 2>": ["conv3x3_split_kernel<4, true, true, 2>"],
-    "conv3x3_split_kernel<4, false, false, 2>": ["conv3x3_split_kernel<4, false, false, 2>"],
+    "conv3x3_split_kernel<4, true, false, 2, 3>": ["conv3x3_split_kernel<4, true, false, 2, 3>"],
+    "conv3x3_split_kernel<4, true, true, 2, 3>": ["conv3x3_split_kernel<4, true, true, 2, 3>"],
+    "conv3x3_split_kernel<4, false, false, 2, 3>": ["conv3x3_split_kernel<4, false, false, 2, 3>"],
     "split_layer_kernel": ["split_layer_kernel<"],
     "wino_layer_kernel": ["wino_layer_kernel<false>"],
     "conv3x3_wino2d_kernel[|prelu|||]": ["conv3x3_wino2d_kernel<2, false, true>"],
