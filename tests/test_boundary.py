@@ -80,6 +80,29 @@ def test_couple_row_interleaving(built_lib):
     assert L.cwfa_conv3x3_split_couple_f32(None, None, None, 1, 8, 8, 8, 0, ctypes.byref(cp), None) == -2
 
 
+def test_layout_and_two_source_options_are_validated(built_lib):
+    """The options added for the sub-network maps are rejected where they do not apply (no launch happens: no GPU here)."""
+    from cwfa_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    o = _lib.ConvOpts()
+    o.in_cat, o.in_cat_from, o.in_cat_c1 = p.value, 24, 24                 # in_cat_from must be a multiple of 16
+    assert L.cwfa_conv2d_f32(p, p, p, 1, 72, 8, 8, 64, 1, 4608, 4096, ctypes.byref(o), None) == -1
+    assert b"in_cat" in L.cwfa_last_error()
+    o = _lib.ConvOpts()
+    o.out_blocked8 = 1                                                       # blocked output: 1x1 banks only here
+    assert L.cwfa_conv2d_f32(p, p, p, 1, 64, 8, 8, 64, 3, 4096, 4096, ctypes.byref(o), None) == -1
+    o = _lib.ConvOpts()
+    o.in_blocked8 = 1                                                        # blocked input is read by the split 3x3 kernel only
+    assert L.cwfa_conv2d_f32(p, p, p, 1, 64, 8, 8, 64, 1, 4096, 4096, ctypes.byref(o), None) == -1
+    assert L.cwfa_subnet_layer_split_f32(p, p, p, p, p, 1, 8, 8, 4096, 4096, 7, None) == -1        # layout not in 0..3
+    assert L.cwfa_subnet_layer_split_group_f32(p, p, p, p, p, 6, 1, 8, 8, 4096, 4096, 0, None) == -2  # more than 5 problems
+    assert L.cwfa_subnet_layer_split_max_problems() == 5
+    assert L.cwfa_conv7x7_split_packed_bytes(65, 64) == -1 and L.cwfa_conv7x7_split_packed_bytes(64, 64) == 98 * 3 * 4 * 64 * 16
+    assert L.cwfa_haar3d_fwd_f32(p, p, 1, 3, 8, 8, 1, 0.5, 192, None) == -2                         # odd depth
+
+
 def test_ops_fail_loudly_on_cpu_tensors(built_lib):
     from cwfa_amd import ops
     from cwfa_amd.INN_utils import HaarTransform1D
