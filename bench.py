@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--no-virtual-cat", action="store_true", help="(ablation, block types other than CAT) materialise the input "
                     "cat(half, condition) of every coupling sub-network instead of reading it from its two tensors")
     ap.add_argument("--no-split7x7", action="store_true", help="(ablation) the ConvNeXt 7x7 convolution on the fp32 MFMA kernel")
+    ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
     ap.add_argument("--group-layers", action="store_true", help="(ablation) the k-th residual layers of the five independent sub-networks "
                     "of a CAT step in one grouped launch instead of one launch per sub-network and layer (measured: no gain)")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
@@ -221,6 +222,8 @@ def main():
         ops.VIRTUAL_CAT = False
     if a.no_split7x7:
         ops.SPLIT_7X7 = False
+    if a.no_xcd_map:
+        ops.set_option("split3x3_xcd_map", 0)
     if a.group_layers:
         ops.GROUP_LAYERS = True
     if a.split3x3_min is not None:

@@ -719,6 +719,7 @@ int launch(const ConvParams& p, int epi, hipStream_t st) {
 
 }  // namespace
 int g_cwfa_split_products = 6;
+int g_cwfa_split_xcd_map = 1;
 namespace {
 
 int fill_params(ConvParams& p, const char* name, const float* x, const float* w_packed, float* y, int B, int Cin, int H,
@@ -1044,6 +1045,10 @@ extern "C" int cwfa_set_option(const char* name, int value) {
     }
     if (strcmp(name, "wgrad_rows") == 0) {          // 0: the 3x3 weight gradient always takes its first (register-staged) form
         g_cwfa_wgrad_rows = value;
+        return CWFA_OK;
+    }
+    if (strcmp(name, "split3x3_xcd_map") == 0) {    // (ablation) 0: blocks of the split 3x3 kernel in plain (spatial tile, cout tile) order
+        g_cwfa_split_xcd_map = value;
         return CWFA_OK;
     }
     if (strcmp(name, "split_products") == 0) {      // 6: fp32-accurate split; 1: plain bf16 operands (BASELINE configs[4])

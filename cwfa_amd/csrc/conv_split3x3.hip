@@ -28,6 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
+extern int g_cwfa_split_xcd_map;        // conv2d.hip ("split3x3_xcd_map" option)
 
 namespace {
 
@@ -61,7 +62,7 @@ struct SParams {
     const float* x;
     const void* wp;
     float* y;
-    int B, Cin, H, W, Cout, nchunks, nsteps, tiles_x;
+    int B, Cin, H, W, Cout, nchunks, nsteps, tiles_x, ntiles, ctiles, xcd_map;
     int64_t x_bs, y_bs;
     cwfa_conv_opts o;
     cwfa_couple cp;             // EPI_COUPLE only
@@ -138,8 +139,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     constexpr int NQ = SIX ? 3 : 1;
     constexpr int OFF_W = 2 * XB;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    const int b = blockIdx.z, ct = blockIdx.y;
-    const int row0 = (blockIdx.x / p.tiles_x) * TR, col0 = (blockIdx.x % p.tiles_x) * TC;
+    // XCD-aware block -> (spatial tile, cout tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks L and L + 8 share
+    // an L2): XCD x works through its own contiguous band of spatial tiles (row-major: halo rows are re-read from that L2) with the
+    // cout tiles of one spatial tile in consecutive slots, so the second .. fourth read of an input tile hits L2, not the fabric.
+    const int b = blockIdx.z;
+    int sp, ct;
+    if (p.xcd_map && (p.ntiles & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        sp = xcd * (p.ntiles >> 3) + slot / p.ctiles;
+        ct = slot % p.ctiles;
+    } else {
+        sp = blockIdx.x / p.ctiles;
+        ct = blockIdx.x % p.ctiles;
+    }
+    const int row0 = (sp / p.tiles_x) * TR, col0 = (sp % p.tiles_x) * TC;
 
     // ---- staging entries (two per thread): k = 0: k half wave >> 2, entries 0..255; k = 1: entries 256..339 of k half
     // (wave >> 1) & 1 for waves 0..3 (so that the k half, hence the channel, is uniform over a wave)
@@ -551,7 +564,15 @@ int launch(const SParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles_y = (p.H + TR - 1) / TR, ctiles = (p.Cout + G::CT - 1) / G::CT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * tiles_y), ctiles, p.B), dim3(512), G::LDS, stream, p);
+    SParams q = p;
+    q.ntiles = p.tiles_x * tiles_y;
+    q.ctiles = ctiles;
+    q.xcd_map = g_cwfa_split_xcd_map;
+    if ((int64_t)q.ntiles * ctiles >= (1ll << 31)) {
+        cwfa_set_error("cwfa_conv3x3_split_f32: grid too large");
+        return CWFA_E_SHAPE;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.ntiles * ctiles), 1, p.B), dim3(512), G::LDS, stream, q);
     CWFA_LAUNCH_CHECK("cwfa_conv3x3_split_f32");
     return CWFA_OK;
 }

@@ -50,9 +50,14 @@ const char* cwfa_last_error(void);
 /* process-wide tuning options (set before packing weights; pack and launch consult the same value):
  *   "winograd_min_cout" : 3x3 convolutions with at least this many output channels use the Winograd kernels
  *                         (default 1; a value above every Cout selects the direct kernels everywhere).
- *   "winograd_2d"       : non-zero: layers with more than 64 output channels use the 2-D F(2x2,3x3) kernel
- *                         (experimental: +1..13 % on plain convolutions, slower with a load-side prologue);
- *                         0 (default): the 1-D F(2,3) kernel as for the narrower layers.
+ *   "winograd_2d"       : v > 0: layers with more than 64 and at least v output channels use the 2-D F(2x2,3x3) kernel
+ *                         (+1..13 % on plain convolutions, slower with a load-side prologue); 0: the 1-D F(2,3) kernel
+ *                         as for the narrower layers.
+ *   "split_products"    : 6 (default): the split-bf16 kernels form every fp32 product from six bf16 products
+ *                         (fp32-equivalent); 1: plain bf16 operands (BASELINE.json configs[4]).
+ *   "wgrad_rows"        : 0: the 3x3 weight gradient always takes its first (register-staged) form.
+ *   "split3x3_xcd_map"  : 0: (ablation) blocks of the split 3x3 kernel in plain (spatial tile, cout tile) order instead of
+ *                         the XCD-aware one.
  * returns 0, or CWFA_E_INVAL for an unknown name. */
 int cwfa_set_option(const char* name, int value);
 
