@@ -39,6 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
+extern int g_cwfa_split_xcd_map;        // conv2d.hip ("split3x3_xcd_map" option; also the tile walk of this kernel)
 
 namespace {
 
@@ -65,6 +66,7 @@ struct LParams {
     int B, H, W, tiles_x, tiles_y, ntiles;
     int64_t x_bs, y_bs;
     int in_blocked, out_blocked;      // layout of x / y: 0 = NCHW planes, 1 = [C/8][H][W][8] (see the header comment)
+    int xcd_map;
     int nprob, spp;                   // grouped launch: sample b belongs to problem b / spp, which has its own packed image (wp + problem *
                                       // NSL * WSL) and biases (b3 / b1 + problem * 64); nprob = 1: one bank for the whole batch
 };
@@ -143,7 +145,12 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     auto rsrc_of = [&](const float* base) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 64 * plane, 0x00020000);
     };
-    auto tile_coords = [&](int tile, int& b, int& row0, int& col0) {
+    // XCD-aware walk: workgroup w sits on XCD w & 7 (round-robin dispatch), so the k-th tile of workgroup w -- logical index
+    // w + k * gridDim.x -- is taken from XCD (w & 7)'s own contiguous eighth of the tile list: neighbouring tiles (shared halo
+    // rows / columns) are then read through ONE L2 instead of eight.
+    const bool xmap = p.xcd_map && (p.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+    auto tile_coords = [&](int it, int& b, int& row0, int& col0) {
+        const int tile = xmap ? (it & 7) * (p.ntiles >> 3) + (it >> 3) : it;
         const int per = p.tiles_x * p.tiles_y;
         b = tile / per;
         const int rem = tile - b * per;
@@ -550,6 +557,7 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     p.out_blocked = (layout >> 1) & 1;
     p.nprob = nprob;
     p.spp = spp;
+    p.xcd_map = g_cwfa_split_xcd_map;
     p.tiles_x = (W + TC - 1) / TC;
     p.tiles_y = (H + TR - 1) / TR;
     const int64_t ntiles = (int64_t)p.tiles_x * p.tiles_y * B;
