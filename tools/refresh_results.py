@@ -37,7 +37,7 @@ Same line: runner-up `{r2['kernel'].split(' (')[0]}` {r2['algorithmic_tflops']:.
 
 CPU baseline (oracle, torch CPU): {cb['value']:.4f} volumes/s on {cb['cores']} threads of {cb.get('cpu_model', '?')} ({cb['sample']}) — GPU/CPU = {d['value'] / cb['value']:.0f}×; reported for context, the roofline fraction is the figure of merit.
 
-Dominant kernel traffic (`profiles/{TAG}_pmc_traffic.json`): {(r['traffic'] or 0) / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (input once + output once): every 256-channel cout tile reads the input again (1 / 2 / 4 tiles for 256 / 512 / 1024 outputs) plus the 10/8 × 34/32 halo of a tile, where it misses that XCD's L2; the layer kernel {(r2['traffic'] or 0) / 1e6:.0f} MB vs {r2['algorithmic_bytes_per_launch'] / 1e6:.0f} MB.  `avg_launch_ms` of `{dom_name}`: {r['avg_launch_ms']:.3f} (HIP events inside bench.py's timed region) vs {avg_dom:.3f} (rocprofv3 `AverageNs` of the same kernel name over the whole profiled run); of `{r2['kernel'].split(' (')[0]}` (all map-layout instantiations): {r2['avg_launch_ms']:.4f} vs {avg_r2:.4f}.
+Dominant kernel traffic (`profiles/{TAG}_pmc_traffic.json`): {(r['traffic'] or 0) / 1e6:.0f} MB per launch HBM-side (FETCH_SIZE×2 + WRITE_SIZE) vs {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (input once + output once) -- 805 MB before the XCD-aware block order: what is left is the first read of an input tile by the XCD that owns it plus the 10/8 × 34/32 halo where it misses that L2; the layer kernel {(r2['traffic'] or 0) / 1e6:.0f} MB vs {r2['algorithmic_bytes_per_launch'] / 1e6:.0f} MB.  `avg_launch_ms` of `{dom_name}`: {r['avg_launch_ms']:.3f} (HIP events inside bench.py's timed region) vs {avg_dom:.3f} (rocprofv3 `AverageNs` of the same kernel name over the whole profiled run); of `{r2['kernel'].split(' (')[0]}` (all map-layout instantiations): {r2['avg_launch_ms']:.4f} vs {avg_r2:.4f}.
 
 Per-kernel time per volume (rocprofv3 `--kernel-trace --stats` over `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-experiment`, `profiles/{TAG}_bench_kernel_stats.csv`; {steps} volumes in the trace):
 {table}
