@@ -1481,3 +1481,29 @@ def test_split_fused_layer_is_fp32_accurate(shape):
     ref = F.elu(F.conv2d(F.elu(F.conv2d(xd, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + xd)
     y = ops.subnet_layer(x.cuda(), ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda())
     assert_close(y, ref, 3e-6, "split fused layer")
+
+
+@pytest.mark.parametrize("extra", [[], ["--block-type", "GLOW"], ["--precision", "fp32"]])
+def test_bench_line_contract_at_a_small_size(extra):
+    """bench.py end to end on a small workload (flows + condition nets only: the LRNN's mean branch is hard-wired to 512^2): ONE
+    JSON line with the contract's keys, a roofline fraction <= 1 on a kernel family that is named like the rocprofv3 kernel, and
+    an in-path DWT figure."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-lrnn", "--side", "128", "--depths", "32", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-experiment", *extra], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_dwt"):
+        assert k in d, k
+    assert d["unit"] == "volumes/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and rf["achieved"] / rf["peak"] == pytest.approx(rf["frac"])
+    assert d["roofline_dwt"]["bound"] == "hbm" and 0 < d["roofline_dwt"]["frac"] <= 1.0
