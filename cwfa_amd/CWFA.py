@@ -6,7 +6,6 @@ Out of scope: experiment management of ``run_CWFA``
 TensorBoard, metrics, figures, TIFF export.
 """
 import math
-from typing import List, Optional, Sequence
 
 import torch
 
