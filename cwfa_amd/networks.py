@@ -17,7 +17,6 @@ import glob
 import math
 import re
 
-import numpy as np
 import torch
 import torch.nn as nn
 
