@@ -42,6 +42,7 @@ SPLIT_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product 
 WINO2D_MIN = 512      # the library's "winograd_2d" default (ops.WINOGRAD_2D_DEFAULT); --wino2d overrides both
 
 
+ROWS16 = True         # the library's "split3x3_rows16" option
 SPLIT_SIX = True      # six bf16 products per fp32 product (False in --precision bf16); part of the split kernels' template arguments
 
 
@@ -52,16 +53,17 @@ def family(key):
     if ks == "L":
         return "split_layer_kernel" if tag.endswith("+split") else "wino_layer_kernel"
     if tag.endswith("+split") and ks == 3:
-        # exactly the rocprofv3 name: conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS> (csrc/conv_split3x3.hip: launch_epi)
+        # exactly the rocprofv3 name: conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS, RPW> (csrc/conv_split3x3.hip: launch_epi)
         pro, act, res, act2, _ = tag.split("|")
         plain = not res and not act2
         act1 = 2 if (plain and act == "prelu") else 0 if (plain and not act and not key[7]) else -1
         if tag.endswith("couple+split"):
             act1 = -2
-        return "conv3x3_split_kernel<%d, %s, %s, %d, 3>" % (4 if cout > 128 else 2 if cout > 64 else 1, "true" if SPLIT_SIX else "false",
-                                                             "true" if key[7] else "false", act1)
+        mpw = 4 if cout > 128 else 2 if cout > 64 else 1
+        rpw = 8 if (ROWS16 and mpw == 1 and H > 8 and act1 in (0, -2)) else 4      # 16-row tiles: the plain 64-channel tiling
+        return "conv3x3_split_kernel<%d, %s, %s, %d, 3, %d>" % (mpw, "true" if SPLIT_SIX else "false", "true" if key[7] else "false", act1, rpw)
     if tag.endswith("+split") and ks == 7:
-        return "conv3x3_split_kernel<1, %s, false, 0, 7>" % ("true" if SPLIT_SIX else "false")
+        return "conv3x3_split_kernel<1, %s, false, 0, 7, 4>" % ("true" if SPLIT_SIX else "false")
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
@@ -74,9 +76,9 @@ def family(key):
 # kernel family (see family()) -> substrings of the rocprofv3 kernel names it covers (tools/pmc_traffic.py averages FETCH_SIZE /
 # WRITE_SIZE over the launches of all of them; the layer kernel has one instantiation per map layout)
 ROCPROF_NAMES = {
-    "conv3x3_split_kernel<4, true, false, 2, 3>": ["conv3x3_split_kernel<4, true, false, 2, 3>"],
-    "conv3x3_split_kernel<4, true, true, 2, 3>": ["conv3x3_split_kernel<4, true, true, 2, 3>"],
-    "conv3x3_split_kernel<4, false, false, 2, 3>": ["conv3x3_split_kernel<4, false, false, 2, 3>"],
+    "conv3x3_split_kernel<4, true, false, 2, 3, 4>": ["conv3x3_split_kernel<4, true, false, 2, 3, 4>"],
+    "conv3x3_split_kernel<4, true, true, 2, 3, 4>": ["conv3x3_split_kernel<4, true, true, 2, 3, 4>"],
+    "conv3x3_split_kernel<4, false, false, 2, 3, 4>": ["conv3x3_split_kernel<4, false, false, 2, 3, 4>"],
     "split_layer_kernel": ["split_layer_kernel<"],
     "wino_layer_kernel": ["wino_layer_kernel<false>"],
     "conv3x3_wino2d_kernel[|prelu|||]": ["conv3x3_wino2d_kernel<2, false, true>"],
@@ -186,6 +188,7 @@ def main():
     ap.add_argument("--no-virtual-cat", action="store_true", help="(ablation, block types other than CAT) materialise the input "
                     "cat(half, condition) of every coupling sub-network instead of reading it from its two tensors")
     ap.add_argument("--no-split7x7", action="store_true", help="(ablation) the ConvNeXt 7x7 convolution on the fp32 MFMA kernel")
+    ap.add_argument("--no-rows16", action="store_true", help="(ablation) 8-row tiles for the 64-channel tiling of the split 3x3 kernel")
     ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
     ap.add_argument("--group-layers", action="store_true", help="(ablation) the k-th residual layers of the five independent sub-networks "
                     "of a CAT step in one grouped launch instead of one launch per sub-network and layer (measured: no gain)")
@@ -224,6 +227,10 @@ def main():
         ops.SPLIT_7X7 = False
     if a.no_xcd_map:
         ops.set_option("split3x3_xcd_map", 0)
+    if a.no_rows16:
+        global ROWS16
+        ROWS16 = False
+        ops.set_option("split3x3_rows16", 0)
     if a.group_layers:
         ops.GROUP_LAYERS = True
     if a.split3x3_min is not None:

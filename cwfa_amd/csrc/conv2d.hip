@@ -720,6 +720,7 @@ int launch(const ConvParams& p, int epi, hipStream_t st) {
 }  // namespace
 int g_cwfa_split_products = 6;
 int g_cwfa_split_xcd_map = 1;
+int g_cwfa_split_rows16 = 1;
 namespace {
 
 int fill_params(ConvParams& p, const char* name, const float* x, const float* w_packed, float* y, int B, int Cin, int H,
@@ -1049,6 +1050,10 @@ extern "C" int cwfa_set_option(const char* name, int value) {
     }
     if (strcmp(name, "split3x3_xcd_map") == 0) {    // (ablation) 0: blocks of the split 3x3 kernel in plain (spatial tile, cout tile) order
         g_cwfa_split_xcd_map = value;
+        return CWFA_OK;
+    }
+    if (strcmp(name, "split3x3_rows16") == 0) {     // (ablation) 0: the 64-channel tiling of the split 3x3 kernel always on 8-row tiles
+        g_cwfa_split_rows16 = value;
         return CWFA_OK;
     }
     if (strcmp(name, "split_products") == 0) {      // 6: fp32-accurate split; 1: plain bf16 operands (BASELINE configs[4])

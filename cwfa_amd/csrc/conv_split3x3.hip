@@ -29,32 +29,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
 extern int g_cwfa_split_xcd_map;        // conv2d.hip ("split3x3_xcd_map" option)
+extern int g_cwfa_split_rows16;         // conv2d.hip ("split3x3_rows16" option: 16-row tiles for the 64-channel tiling)
 
 namespace {
 
-constexpr int TR = 8, TC = 32, NT = TR;     // NT: n-tiles per wave (4 rows x 2 halves)
+constexpr int TR = 8, TC = 32;              // default tile: 8 rows x 32 pixels (four rows per wave); XG<KS, 8>: 16 rows
 
 // input-tile geometry of a KS x KS convolution (KS = 3: the form everything above describes; KS = 7: the ConvNeXt convolution of
 // the LRNN, networks.py:488 -- the same kernel with a 3-pixel halo, 49 taps and a 49-step period over two 16-channel chunks)
-template <int KS>
+// RPW = image rows per wave: 4 (tile of 8 rows, 8 n-tiles per wave) or, for the 64-channel tiling of the 3x3, 8 (tile of 16 rows:
+// twice the MFMAs per barrier and per A fragment, 18/16 instead of 10/8 halo rows -- the output convolutions of the sub-networks,
+// whose K = 9 x 64 is too short to amortise a tile's fill and drain on 8 rows)
+template <int KS, int RPW = 4>
 struct XG {
-    static constexpr int PAD = KS / 2, XR = TR + 2 * PAD, XC = TC + 2 * PAD, NTAP = KS * KS;
-    static constexpr int EPK = XR * XC;                 // entries per k half: 306 (3x3), 532 (7x7)
+    static constexpr int TRW = 2 * RPW, NT = 2 * RPW;   // tile rows; n-tiles per wave (RPW rows x 2 halves of 16 pixels)
+    static constexpr int PAD = KS / 2, XR = TRW + 2 * PAD, XC = TC + 2 * PAD, NTAP = KS * KS;
+    static constexpr int EPK = XR * XC;                 // entries per k half: 306 (3x3), 612 (3x3, 16 rows), 532 (7x7)
     // bytes of one k-half plane: EPK x 16 padded so that the two k halves differ by 64 bytes modulo 256 (bank phase):
-    // 3x3: 4896 -> 5440;  7x7: 8512 already is
-    static constexpr int KHB = KS == 3 ? 5440 : 8512;
+    // 3x3: 4896 -> 5440;  3x3 on 16 rows: 9792 and 7x7: 8512 already are
+    static constexpr int KHB = KS == 7 ? 8512 : RPW == 8 ? 9792 : 5440;
     static constexpr int XPB = 2 * KHB;                 // one piece plane
-    static constexpr int XB = 3 * XPB;                  // one input buffer (3x3: 30 720; 7x7: 51 072)
-    static constexpr int NEK = KS == 3 ? 2 : 3;         // staging entries per thread and chunk
+    static constexpr int XB = 3 * XPB;                  // one input buffer (3x3: 32 640 / 58 752; 7x7: 51 072)
+    static constexpr bool SPECIAL = KS == 3 && RPW == 4;        // the two-entry staging map with a wave-uniform k half
+    static constexpr int NEK = SPECIAL ? 2 : 3;         // staging entries per thread and chunk
     static_assert(EPK * 16 <= KHB && KHB % 256 == 64 && 2 * EPK <= 512 * NEK, "staging entry map");
-    static_assert(KS != 3 || (EPK > 256 && EPK <= 384), "3x3 staging entry map");
+    static_assert(!SPECIAL || (EPK > 256 && EPK <= 384), "3x3 staging entry map");
+    static_assert(KS == 3 || RPW == 4, "7x7: 8-row tiles");
 };
 
-template <int MPW, int KS = 3>
+template <int MPW, int KS = 3, int RPW = 4>
 struct Geo {
     static constexpr int CT = 64 * MPW;                 // output channels per block
     static constexpr int WSL = 3 * 4 * CT * 16;         // bytes of one weight slice (K = 32)
-    static constexpr int LDS = 2 * XG<KS>::XB + 2 * WSL;    // 3x3, MPW = 4: 159 744;  7x7, MPW = 1: 126 720
+    static constexpr int LDS = 2 * XG<KS, RPW>::XB + 2 * WSL;   // 3x3, MPW = 4: 163 584 ... see the static_assert
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -105,8 +112,8 @@ __device__ __forceinline__ float act_of(float v, float alpha) {
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // byte offset of the B fragments of tap t in buffer `buf`, relative to the lane base
-template <int KS>
-__host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XG<KS>::XB + ((tap / KS) * XG<KS>::XC + tap % KS) * 16; }
+template <int KS, int RPW>
+__host__ __device__ constexpr int tap_off(int buf, int tap) { return buf * XG<KS, RPW>::XB + ((tap / KS) * XG<KS, RPW>::XC + tap % KS) * 16; }
 
 enum { EPI_RUNTIME = -1, EPI_COUPLE = -2 };
 
@@ -122,11 +129,12 @@ __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
 
 // ADD: a second tensor is added on load (UNet skip); ACT1: compile-time activation of the common epilogues (bias -> ACT1),
 // EPI_RUNTIME = whatever cwfa_conv_opts says (bias -> act -> + residual -> act2)
-template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3>
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
-    typedef XG<KS> G;
-    constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD;
-    static_assert(KS == 3 || (MPW == 1 && !ADD), "7x7: the 64-channel tiling without a skip add");
+    typedef XG<KS, RPW> G;
+    constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD, NT = G::NT;
+    constexpr bool SPECIAL = G::SPECIAL;
+    static_assert(SPECIAL || (MPW == 1 && !ADD), "7x7 / 16-row tiles: the 64-channel tiling without a skip add");
     constexpr int CT = 64 * MPW;                        // output channels per block
     constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         sp = blockIdx.x / p.ctiles;
         ct = blockIdx.x % p.ctiles;
     }
-    const int row0 = (sp / p.tiles_x) * TR, col0 = (sp % p.tiles_x) * TC;
+    const int row0 = (sp / p.tiles_x) * G::TRW, col0 = (sp % p.tiles_x) * TC;
 
     // ---- staging entries (two per thread): k = 0: k half wave >> 2, entries 0..255; k = 1: entries 256..339 of k half
     // (wave >> 1) & 1 for waves 0..3 (so that the k half, hence the channel, is uniform over a wave)
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     int ekh[NEK], eidx[NEK];
     bool fin[NEK];
     unsigned fo[NEK];
-    if constexpr (KS == 3) {
+    if constexpr (SPECIAL) {
         ekh[0] = wave >> 2; eidx[0] = tid & 255; fin[0] = true;
         ekh[1] = (wave >> 1) & 1; eidx[1] = 256 + (tid & 127); fin[1] = wave < 4 && eidx[1] < EPK;
     } else {
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         // blocked input ([Cin/8][H][W][8], cwfa_conv_opts.in_blocked8): the 32-byte entry of the pixel; its channel block rides
         // in the scalar offset
         fo[k] = !fok[k] ? OOB : p.o.in_blocked8 ? (unsigned)((gr * p.W + gc) * 32) : (unsigned)((gr * p.W + gc) * 4);
-        if constexpr (KS != 3) fo[k] = !fok[k] ? OOB : fo[k] + (unsigned)(ekh[k] * 8) * (unsigned)plane;
+        if constexpr (!SPECIAL) fo[k] = !fok[k] ? OOB : fo[k] + (unsigned)(ekh[k] * 8) * (unsigned)plane;    // (either layout: 8 planes)
     }
     const int xbytes = p.Cin * plane;                   // channels >= Cin: out of range, 0.0
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)b * p.x_bs), 0, xbytes, 0x00020000);
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 
     auto load_entry = [&](auto kc, float (&xv)[8], float (&av)[8], int chunk) {
         constexpr int k = decltype(kc)::value;
-        const int ch0 = chunk * 16 + (KS == 3 ? ekh[k] * 8 : 0);        // (7x7: the k half is in the lane's offset)
+        const int ch0 = chunk * 16 + (SPECIAL ? ekh[k] * 8 : 0);        // (otherwise the k half is in the lane's offset)
         if (KS == 3 && !ADD && p.o.in_blocked8) {                  // (uniform) channel block ch0 / 8 = 8 planes' worth of bytes each (the
                                                         // load-side affine is per channel: unchanged)
             const f32x4 lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, fo[k], ch0 * plane, 0));
@@ -220,8 +228,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     };
     auto store_entry = [&](auto kc, const float (&xv)[8], const float (&av)[8], int chunk, int buf) {
         constexpr int k = decltype(kc)::value;
-        if (KS == 3 && k == 1 && !fin[1]) return;
-        const int ch0 = chunk * 16 + ekh[k] * 8;          // wave-uniform (3x3): the affine tables are read through scalar loads
+        if (SPECIAL && k == 1 && !fin[1]) return;
+        const int ch0 = chunk * 16 + ekh[k] * 8;          // wave-uniform (two-entry map): the affine tables are read through scalar loads
         bf16x8 pc[3];
         float scv[8], shv[8];
         if (has_aff) {
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
             pc[0][j] = a1; pc[1][j] = a2; pc[2][j] = a3;
         }
         char* dst = lds + buf * XB + ekh[k] * KHB + eidx[k] * 16;
-        if (KS == 3 || fin[k]) {
+        if (SPECIAL || fin[k]) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) *reinterpret_cast<bf16x8*>(dst + q * XPB) = pc[q];
         }
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     };
 
     const int alane = OFF_W + (g * CT + wm * MPW * 16 + c16) * 16;        // + slot*WSL + (q*4*CT + mt*16)*16
-    const int blane = (g & 1) * KHB + (wn * 4 * XC + c16) * 16;              // + tap_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
+    const int blane = (g & 1) * KHB + (wn * RPW * XC + c16) * 16;            // + tap_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
     const bool sel = (g >> 1) != 0;
 
     f32x4 acc[MPW][NT];
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    read_b(0, blane + (sel ? tap_off<KS>(0, 1) : tap_off<KS>(0, 0)), 0);  // step 0: taps 0 | 1 of chunk 0
+    read_b(0, blane + (sel ? tap_off<KS, RPW>(0, 1) : tap_off<KS, RPW>(0, 0)), 0);  // step 0: taps 0 | 1 of chunk 0
     // ONE step as the body of a rolled loop (the accumulators are loop-carried values: unrolling the nine steps of a period
     // makes the register allocator split their live ranges and keep copies); P = position in the 9-step period
     int sl = 0, P = 0, ce = 0;                           // ring slot of this step's slice; period position; even chunk of the period
@@ -321,7 +329,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         // staging schedule inside a period: the odd buffer is free from step 0 (stores SB + k of the entries loaded in the period
         // before), the even one right after the step that pairs tap NTAP-1 with the odd chunk's tap 0 (stores SA + k, loads LA + k
         // a few steps earlier); the odd chunk after next is loaded at LB + k
-        constexpr int SB = 0, SA = KS == 3 ? 5 : 26, LA = KS == 3 ? 2 : 22, LB = KS == 3 ? 6 : 44;
+        constexpr int SB = 0, SA = KS == 3 ? 5 : 26, LA = KS == 3 ? 2 : 22, LB = KS == 3 ? 6 : 44;       // (+ k < NEK: all below NTAP)
+        static_assert(LB + NEK - 1 < NTAP && LA + NEK - 1 < SA, "staging schedule");
         // -- order matters: in this rolled loop the compiler cannot count the vector-memory operations between a staging load
         // and its use, so it waits for ALL of them (vmcnt(0)) before the split below: that must come BEFORE this step issues
         // its own DMA and loads, when everything older has long landed (after them it cost 2 - 9 thousand cycles per step).
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         float ssum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int row = row0 + wn * 4 + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const int row = row0 + wn * RPW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
             const bool ok = row < p.H && col < p.W;
             const unsigned po = ok ? (unsigned)((row * p.W + col) * 4) + jlane : OOB;
             float xv[NP];
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
             bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int row = row0 + wn * 4 + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const int row = row0 + wn * RPW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
             if constexpr (ACT1 != EPI_RUNTIME) {
                 if (outb) {
                     f32x4 o4;
@@ -550,10 +559,11 @@ __global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restr
 inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 64 ? 2 : 1; }
 inline int nsteps_of(int Cin, int ntap = 9) { return ntap * (((Cin + 15) / 16 + 1) / 2); }   // whole periods of two 16-channel chunks
 
-template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3>
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4>
 int launch(const SParams& p, hipStream_t stream) {
-    typedef Geo<MPW, KS> G;
-    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS>;
+    typedef Geo<MPW, KS, RPW> G;
+    constexpr int TRW = XG<KS, RPW>::TRW;
+    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS, RPW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -563,7 +573,7 @@ int launch(const SParams& p, hipStream_t stream) {
         }
         attr_set = true;
     }
-    const int tiles_y = (p.H + TR - 1) / TR, ctiles = (p.Cout + G::CT - 1) / G::CT;
+    const int tiles_y = (p.H + TRW - 1) / TRW, ctiles = (p.Cout + G::CT - 1) / G::CT;
     SParams q = p;
     q.ntiles = p.tiles_x * tiles_y;
     q.ctiles = ctiles;
@@ -642,7 +652,11 @@ extern "C" int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packe
                  "cwfa_conv3x3_split_couple_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const bool six = g_cwfa_split_products != 1;
-    if (p.Cout == 64) return six ? launch<1, true, false, EPI_COUPLE>(p, st) : launch<1, false, false, EPI_COUPLE>(p, st);
+    if (p.Cout == 64) {
+        if (g_cwfa_split_rows16 && H > 8)       // 16-row tiles (no load-side prologue here by construction)
+            return six ? launch<1, true, false, EPI_COUPLE, 3, 8>(p, st) : launch<1, false, false, EPI_COUPLE, 3, 8>(p, st);
+        return six ? launch<1, true, false, EPI_COUPLE>(p, st) : launch<1, false, false, EPI_COUPLE>(p, st);
+    }
     return six ? launch<2, true, false, EPI_COUPLE>(p, st) : launch<2, false, false, EPI_COUPLE>(p, st);
 }
 
@@ -700,6 +714,9 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     const bool six = g_cwfa_split_products != 1;
     if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
     if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
+    // 64-channel tiling: 16-row tiles for the plain bias-only form (the output convolutions of the sub-networks)
+    if (g_cwfa_split_rows16 && H > 8 && !p.o.in_scale && !p.o.in_add && !p.o.residual && p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE)
+        return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8>(p, st);
     return six ? launch_epi<1, true>(p, st) : launch_epi<1, false>(p, st);
 }
 

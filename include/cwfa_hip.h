@@ -58,6 +58,7 @@ const char* cwfa_last_error(void);
  *   "wgrad_rows"        : 0: the 3x3 weight gradient always takes its first (register-staged) form.
  *   "split3x3_xcd_map"  : 0: (ablation) blocks of the split 3x3 kernel in plain (spatial tile, cout tile) order instead of
  *                         the XCD-aware one.
+ *   "split3x3_rows16"   : 0: (ablation) the 64-channel tiling of the split 3x3 kernel always on 8-row tiles.
  * returns 0, or CWFA_E_INVAL for an unknown name. */
 int cwfa_set_option(const char* name, int value);
 
