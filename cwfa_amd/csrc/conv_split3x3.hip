@@ -121,7 +121,7 @@ enum { EPI_RUNTIME = -1, EPI_COUPLE = -2 };
 __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
     switch (kind) {
         case CWFA_CLAMP_ATAN: return clamp * (0.636f * cwfa_atan(a));
-        case CWFA_CLAMP_TANH: return clamp * tanhf(a);
+        case CWFA_CLAMP_TANH: return clamp * cwfa_tanh(a);
         case CWFA_CLAMP_SIGMOID: return clamp * (2.f * (1.f / (1.f + expf(-a)) - 0.5f));
         default: return clamp * a;
     }
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                 else tr = acc[MPW - 1][nt][k] + bt[k];
                 const float sv = soft_clamp(sr * cp.pre_scale, cp.clamp_kind, cp.clamp);
                 const float tv = tr * cp.pre_scale;
-                const float yv = cp.rev ? (xv[k] - tv) * expf(-sv) : expf(sv) * xv[k] + tv;
+                const float yv = cp.rev ? (xv[k] - tv) * __expf(-sv) : __expf(sv) * xv[k] + tv;     // |s| <= clamp: v_exp_f32, rel. error ~2e-7
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), cy, po, (jwave + k) * plane, 0);
                 ssum += ok ? sv : 0.f;
             }

@@ -341,7 +341,7 @@ extern "C" int cwfa_gather_f32(const float* x, const int64_t* perm, float* y, in
 __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
     switch (kind) {
         case CWFA_CLAMP_ATAN: return clamp * (0.636f * cwfa_atan(a));
-        case CWFA_CLAMP_TANH: return clamp * tanhf(a);
+        case CWFA_CLAMP_TANH: return clamp * cwfa_tanh(a);
         case CWFA_CLAMP_SIGMOID: return clamp * (2.f * (1.f / (1.f + expf(-a)) - 0.5f));
         default: return clamp * a;
     }
