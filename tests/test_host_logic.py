@@ -194,3 +194,44 @@ def test_mean_volume_cache_file_round_trip(tmp_path):
     CWFA.save_mean_volume_cache(str(q), got)
     again = CWFA.load_mean_volume_cache(str(q))
     assert all(torch.equal(a, b) for a, b in zip(again, got))
+
+
+def test_plan_lowering_of_actnorm_and_mixed_graphs_on_cpu():
+    """Graph construction and plan lowering are host logic (no kernel runs): a step graph with ActNorm nodes keeps a plan whose
+    chain carries 'act' stages and asks for the node walk until the ActNorms are initialised; a GLOW graph lowers to the mixed
+    plan with the [CAT, permutation] prefix fused; a graph whose Haar node has rebalance != 1 falls back to the node walk."""
+    from cwfa_amd import networks as N, INN_utils
+    from cwfa_amd.FrEIA import framework as Ff, modules as Fm
+    N.networks_n_chans = 8
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    def graph(block, actnorm, rebalance=1.0):
+        D, H, W = 8, 8, 16
+        nodes = [Ff.InputNode(D, H, W, name="input")]
+        nodes.append(Ff.Node(nodes[-1], INN_utils.HaarTransform1D, {"order_by_wavelet": True, "rebalance": rebalance}, name="haar"))
+        split = Ff.Node(nodes[-1], Fm.Split, {"section_sizes": (D // 2, D // 2), "dim": 0}, name="split")
+        nodes.append(split)
+        cond = Ff.ConditionNode(D // 2, H, W, name="cond")
+        nodes.append(cond)
+        nodes.append(Ff.Node(split.out1, Fm.ConditionalAffineTransform, {"subnet_constructor": N.wavelet_flow_subnetwork2D},
+                             conditions=[cond], name="cat0"))
+        if actnorm:
+            nodes.append(Ff.Node(nodes[-1], Fm.ActNorm, {}, name="an0"))
+        nodes.append(Ff.Node(nodes[-1], Fm.PermuteRandom, {"seed": 1}, name="p1"))
+        nodes.append(Ff.Node(nodes[-1], block, {"subnet_constructor": N.wavelet_flow_subnetwork2D}, conditions=[cond], name="b1"))
+        nodes.append(Ff.OutputNode(nodes[-1], name="z"))
+        nodes.append(Ff.OutputNode(split.out0, name="low"))
+        return Ff.GraphINN(nodes)
+
+    g = graph(Fm.ConditionalAffineTransform, True)
+    assert [k for k, _ in g._plan.chain] == ["cat", "act", "perm", "cat"] and g._plan.needs_walk() and not hasattr(g._plan, "rest")
+    g.load_state_dict(g.state_dict())                      # loading a checkpoint switches the data-dependent initialisation off
+    assert not g._plan.needs_walk()
+    g = graph(Fm.GLOWCouplingBlock, False)
+    assert [k for k, _ in g._plan.fused] == ["cat", "perm"] and [k for k, _ in g._plan.rest] == ["blk"]
+    try:
+        g = graph(Fm.ConditionalAffineTransform, False, rebalance=0.5)
+    except TypeError:
+        return                                             # this HaarTransform1D takes no rebalance argument: nothing to check
+    assert g._plan is None
