@@ -146,6 +146,75 @@ __global__ void bn_fold_kernel(const double* __restrict__ stats, double count, c
     }
 }
 
+// Everything that follows the statistics pass of a train-mode BatchNorm2d in ONE launch (the inference path issued a fill, the
+// fold, the running-buffer update and three elementwise kernels for the dropout mask per layer -- ~40 tiny launches per volume):
+// (scale, shift) as bn_fold_kernel; running_mean / running_var / num_batches_tracked as bn_running_update_kernel; the dropout
+// factor from the raw uniform draw, m = (u >= p) / (1 - p) (F.dropout2d, unet.py:80,86); and the statistics buffer is zeroed
+// for its next use.
+__global__ void bn_finish_kernel(double* __restrict__ stats, double count, float* __restrict__ rm, float* __restrict__ rv,
+                                 long long* __restrict__ nbt, float momentum, int update_running, const float* __restrict__ w,
+                                 const float* __restrict__ bsh, float eps, const float* __restrict__ mask,
+                                 const float* __restrict__ mask_u, float drop_p, float keep_scale, int B, float* __restrict__ scale,
+                                 float* __restrict__ shift, int C, int zero_stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt && update_running) *nbt += 1;
+    if (c >= C) return;
+    double sc = 1.0, sh = 0.0;
+    if (stats || rm) {
+        double mean, var;
+        if (stats) {
+            const double s1 = stats[2 * c], s2 = stats[2 * c + 1];
+            mean = s1 / count;
+            var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (update_running) {
+                const double var_u = (s2 - s1 * mean) / (count > 1.0 ? count - 1.0 : 1.0);
+                rm[c] = rm[c] * (1.f - momentum) + momentum * (float)mean;
+                rv[c] = rv[c] * (1.f - momentum) + momentum * (float)var_u;
+            }
+            if (zero_stats) stats[2 * c] = stats[2 * c + 1] = 0.0;
+        } else {
+            mean = rm[c];
+            var = rv[c];
+        }
+        sc = (w ? (double)w[c] : 1.0) / sqrt(var + (double)eps);
+        sh = (bsh ? (double)bsh[c] : 0.0) - mean * sc;
+    }
+    if (mask || mask_u) {
+        for (int b = 0; b < B; ++b) {
+            const float m = mask ? mask[b * C + c] : (mask_u[b * C + c] >= drop_p ? 1.f : 0.f) / keep_scale;
+            scale[b * C + c] = (float)sc * m;
+            shift[b * C + c] = (float)sh * m;
+        }
+    } else {
+        scale[c] = (float)sc;
+        shift[c] = (float)sh;
+    }
+}
+
+extern "C" int cwfa_bn_finish_f32(double* stats, double count, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                  float momentum, int update_running, const float* weight, const float* bias, float eps,
+                                  const float* mask_bc, const float* mask_u, float drop_p, float keep_scale, int B, float* scale,
+                                  float* shift, int C, int zero_stats, void* stream) {
+    CWFA_REQUIRE(scale && shift, CWFA_E_INVAL, "cwfa_bn_finish_f32: null output");
+    CWFA_REQUIRE(stats || (running_mean && running_var) || mask_bc || mask_u, CWFA_E_INVAL,
+                 "cwfa_bn_finish_f32: neither batch nor running statistics nor a mask");
+    CWFA_REQUIRE(!running_mean == !running_var, CWFA_E_INVAL, "cwfa_bn_finish_f32: running_mean and running_var go together");
+    CWFA_REQUIRE(!(mask_bc && mask_u), CWFA_E_INVAL, "cwfa_bn_finish_f32: a mask OR a uniform draw");
+    CWFA_REQUIRE(!(mask_bc || mask_u) || B > 0, CWFA_E_INVAL, "cwfa_bn_finish_f32: mask needs B > 0");
+    CWFA_REQUIRE(!mask_u || (drop_p >= 0.f && drop_p < 1.f), CWFA_E_INVAL, "cwfa_bn_finish_f32: 0 <= drop_p < 1");
+    CWFA_REQUIRE(!stats || count > 0, CWFA_E_INVAL, "cwfa_bn_finish_f32: count must be positive");
+    CWFA_REQUIRE(!update_running || (stats && running_mean), CWFA_E_INVAL, "cwfa_bn_finish_f32: the running update needs statistics and buffers");
+    CWFA_REQUIRE(C >= 0, CWFA_E_INVAL, "cwfa_bn_finish_f32: negative size");
+    if (C == 0) return CWFA_OK;
+    CWFA_REQUIRE(!mask_u || keep_scale > 0.f, CWFA_E_INVAL, "cwfa_bn_finish_f32: keep_scale = fp32(1 - p) must be positive");
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, running_mean, running_var,
+                       num_batches_tracked, momentum, update_running, weight, bias, eps, mask_bc, mask_u, drop_p, keep_scale, B, scale,
+                       shift, C, zero_stats);
+    CWFA_LAUNCH_CHECK("cwfa_bn_finish_f32");
+    return CWFA_OK;
+}
+
 // nn.BatchNorm2d's train-mode buffer bookkeeping in one launch (torch/nn/modules/batchnorm.py via unet.py:101-107):
 // running_mean <- (1-m) running_mean + m mean,  running_var <- (1-m) running_var + m var_unbiased,  num_batches_tracked += 1
 __global__ void bn_running_update_kernel(const double* __restrict__ stats, double count, float momentum, float* __restrict__ rm,

@@ -883,12 +883,13 @@ def conv3d_1k1(x, w1, b1, alpha, w2, b2):
 
 
 # ------------------------------------------------------------------------------------------------ LRNN helpers
-def channel_stats(x, blocked=False):
-    """double[2*C]: per-channel (sum, sumsq) over (B,H,W).  ``blocked``: x is a channel-blocked map ([C/8][H][W][8])."""
+def channel_stats(x, blocked=False, out=None):
+    """double[2*C]: per-channel (sum, sumsq) over (B,H,W).  ``blocked``: x is a channel-blocked map ([C/8][H][W][8]).  ``out``: a
+    ZEROED float64[2*C] buffer to add into (bn_finish clears it again) instead of a fresh one."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
-    st = torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
+    st = out if out is not None else torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
     if blocked:
         check(L.cwfa_channel_stats_blocked8_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats_blocked8")
     else:
@@ -918,6 +919,29 @@ def bn_fold(C_, weight=None, bias=None, eps=1e-5, stats=None, count=0.0, running
     shift = torch.empty(n, dtype=torch.float32, device=ref.device)
     check(L.cwfa_bn_fold_f32(_p(stats), float(count), _p(running_mean), _p(running_var), _p(weight), _p(bias),
                              float(eps), _p(mask_bc), B, _p(scale), _p(shift), C_, _stream()), "bn_fold")
+    return scale, shift
+
+
+def bn_finish(C_, weight=None, bias=None, eps=1e-5, stats=None, count=0.0, running_mean=None, running_var=None, momentum=None,
+              num_batches_tracked=None, mask_bc=None, mask_u=None, drop_p=0.0, zero_stats=False):
+    """bn_fold + bn_running_update (``momentum`` not None) in ONE launch; the dropout factor may be given as the raw uniform draw
+    ``mask_u`` [B,C] with ``drop_p`` (m = (u >= p) / (1 - p), exactly F.dropout2d's keep / (1 - p)); ``zero_stats`` clears the
+    statistics buffer for its next accumulation."""
+    L = _lib.lib()
+    ref = next(t for t in (weight, stats, running_mean, mask_bc, mask_u) if t is not None)
+    B, n = 0, C_
+    mk = mask_bc if mask_bc is not None else mask_u
+    if mk is not None:
+        mk = _dev(mk, "mask").contiguous()
+        B = mk.numel() // C_
+        n = B * C_
+    scale = torch.empty(n, dtype=torch.float32, device=ref.device)
+    shift = torch.empty(n, dtype=torch.float32, device=ref.device)
+    upd = momentum is not None and stats is not None and running_mean is not None
+    check(L.cwfa_bn_finish_f32(_p(stats), float(count), _p(running_mean), _p(running_var), _p(num_batches_tracked),
+                               float(momentum or 0.0), int(upd), _p(weight), _p(bias), float(eps), _p(mk if mask_bc is not None else None),
+                               _p(mk if mask_u is not None else None), float(drop_p), float(1.0 - drop_p), B, _p(scale), _p(shift), C_,
+                               int(bool(zero_stats)), _stream()), "bn_finish")
     return scale, shift
 
 

@@ -40,25 +40,59 @@ class _Packed:
         return pc
 
 
-def _bn_affine(bn, y, mask_bc=None, blocked=False):
-    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output; ``blocked``: channel-blocked map)."""
+class _Drop:
+    """A pending F.dropout2d(x, p) (training=True, the functional default the reference relies on, unet.py:80,86): the raw uniform
+    draw [B,C]; the factor (u >= p) / (1 - p) is formed inside the kernel that folds it into a load-side affine (ops.bn_finish)."""
+    __slots__ = ("u", "p")
+
+    def __init__(self, u, p):
+        self.u, self.p = u, p
+
+    def mask(self):
+        return ((self.u >= self.p).to(torch.float32) / (1.0 - self.p)).contiguous()
+
+
+def _bn_affine(bn, y, drop=None, blocked=False):
+    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output; ``blocked``: channel-blocked map), times the
+    pending dropout factor ``drop`` (a _Drop or a ready [B,C] mask).  Train mode: one statistics pass into the layer's own
+    (kept zeroed) float64 buffer, then ONE launch for fold + running-buffer bookkeeping + dropout factor + re-zeroing."""
     C = bn.num_features
+    mu, mb, p = (drop.u, None, drop.p) if isinstance(drop, _Drop) else (None, drop, 0.0)
     if bn.training or not bn.track_running_stats:
-        st = ops.channel_stats(y, blocked=blocked)
+        st = getattr(bn, "_cwfa_stats", None)
+        if st is None or st.device != y.device or getattr(bn, "_cwfa_stats_dirty", False):
+            st = bn._cwfa_stats = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
+        bn._cwfa_stats_dirty = True                          # (an exception before bn_finish leaves it set: the buffer is rebuilt)
+        ops.channel_stats(y, blocked=blocked, out=st)
         n = y.numel() // C
-        if bn.track_running_stats and bn.momentum is not None:       # buffer bookkeeping, as nn.BatchNorm2d does
-            ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
-        return ops.bn_fold(C, bn.weight, bn.bias, bn.eps, stats=st, count=float(n), mask_bc=mask_bc)
-    return ops.bn_fold(C, bn.weight, bn.bias, bn.eps, running_mean=bn.running_mean, running_var=bn.running_var,
-                       mask_bc=mask_bc)
+        track = bn.track_running_stats and bn.momentum is not None       # buffer bookkeeping, as nn.BatchNorm2d does
+        out = ops.bn_finish(C, bn.weight, bn.bias, bn.eps, stats=st, count=float(n), running_mean=bn.running_mean if track else None,
+                            running_var=bn.running_var if track else None, momentum=bn.momentum if track else None,
+                            num_batches_tracked=bn.num_batches_tracked if track else None, mask_bc=mb, mask_u=mu, drop_p=p,
+                            zero_stats=True)
+        bn._cwfa_stats_dirty = False
+        return out
+    return ops.bn_finish(C, bn.weight, bn.bias, bn.eps, running_mean=bn.running_mean, running_var=bn.running_var, mask_bc=mb,
+                         mask_u=mu, drop_p=p)
 
 
 def _drop_mask(p, B, C, device):
-    """F.dropout2d(x, p) (training=True, the functional default the reference relies on): keep-mask / (1-p)."""
+    """F.dropout2d(x, p) as a ready keep-mask / (1-p) tensor (the training path keeps it for its backward)."""
     if not p:
         return None
-    keep = (torch.rand(B, C, device=device) >= p).to(torch.float32)
-    return (keep / (1.0 - p)).contiguous()
+    return _Drop(torch.rand(B, C, device=device), p).mask()
+
+
+def _drop(p, B, C, device):
+    """The same draw, left pending (inference path)."""
+    return _Drop(torch.rand(B, C, device=device), p) if p else None
+
+
+def _drop_affine(C, drop):
+    """A bare dropout factor as a load-side affine."""
+    if isinstance(drop, _Drop):
+        return ops.bn_finish(C, mask_u=drop.u, drop_p=drop.p)
+    return ops.bn_finish(C, mask_bc=drop)
 
 
 class UNetConvBlock(nn.Module):
@@ -128,7 +162,7 @@ class UNetConvBlock(nn.Module):
             if bn is not None:
                 aff = _bn_affine(bn, x, m, blocked=blocked)
             elif m is not None:
-                aff = ops.bn_fold(x.shape[1], mask_bc=m)
+                aff = _drop_affine(x.shape[1], m)
             else:
                 aff = None
         return x, aff
@@ -209,10 +243,10 @@ class UNet(nn.Module):
                 # the normalised full-resolution map is written once for the skip connection
                 x, full = ops.maxpool(x, x.shape[-1] // 2, x.shape[-1] // 2, sc, sh, want_full=True)
                 skips.append(full)
-                m = _drop_mask(self.drop_out, B, x.shape[1], dev)
-                aff = ops.bn_fold(x.shape[1], mask_bc=m) if m is not None else None
+                m = _drop(self.drop_out, B, x.shape[1], dev)
+                aff = _drop_affine(x.shape[1], m) if m is not None else None
         for i, up in enumerate(self.up_path):
-            m = _drop_mask(self.drop_out, B, up.conv_block.block[0].out_channels, dev)
+            m = _drop(self.drop_out, B, up.conv_block.block[0].out_channels, dev)
             x, aff = up.run(x, skips[-i - 1], in_affine=aff, out_mask=m)
         kind, alpha = UNetConvBlock._act(self.last[1])
         sc, sh = aff if aff is not None else (None, None)

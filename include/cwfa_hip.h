@@ -260,6 +260,13 @@ int cwfa_bn_fold_f32(const double* stats, double count, const float* running_mea
                      float* shift, int C, void* stream);
 /* train-mode buffer bookkeeping of nn.BatchNorm2d (unet.py:101-107) from the same statistics: running_mean/var updated
  * with `momentum` (unbiased variance), num_batches_tracked (int64, nullable) incremented. */
+/* cwfa_bn_fold_f32 + cwfa_bn_running_update_f32 in one launch; additionally the dropout factor may be given as the raw uniform
+ * draw (mask_u [B*C], drop_p, keep_scale = fp32(1 - p)): m = (u >= p) / keep_scale, F.dropout2d unet.py:80,86; zero_stats: the
+ * statistics buffer is cleared for its next accumulation (cwfa_channel_stats_f32 adds into it). */
+int cwfa_bn_finish_f32(double* stats, double count, float* running_mean, float* running_var, long long* num_batches_tracked,
+                       float momentum, int update_running, const float* weight, const float* bias, float eps, const float* mask_bc,
+                       const float* mask_u, float drop_p, float keep_scale, int B, float* scale, float* shift, int C, int zero_stats,
+                       void* stream);
 int cwfa_bn_running_update_f32(const double* stats, double count, float momentum, float* running_mean, float* running_var,
                                long long* num_batches_tracked, int C, void* stream);
 /* F.adaptive_max_pool2d(x, (Ho,Wo)) (unet.py:79) with an optional per-channel affine applied BEFORE the max

@@ -1280,6 +1280,41 @@ def test_split_bf16_7x7_is_fp32_accurate(cfg):
     assert_close(y, y32, 5e-6, "split 7x7 vs fp32 MFMA kernel")
 
 
+def test_bn_finish_equals_fold_plus_running_update_plus_mask():
+    """cwfa_bn_finish_f32 = cwfa_bn_fold_f32 + cwfa_bn_running_update_f32 + the dropout factor (u >= p) / (1 - p) formed in the
+    kernel + re-zeroing of the statistics buffer: bit-identical to the separate launches."""
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Cc, H, W = 3, 40, 12, 20
+    y = torch.randn(B, Cc, H, W, generator=g).cuda()
+    w, b = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
+    u = torch.rand(B, Cc, generator=g).cuda()
+    p = 0.3
+    rm0, rv0 = torch.randn(Cc, generator=g).cuda(), (torch.rand(Cc, generator=g) + 0.5).cuda()
+    nbt0 = torch.tensor(7, dtype=torch.int64, device="cuda")
+    n = float(B * H * W)
+    st = ops.channel_stats(y)
+    mask = ((u >= p).to(torch.float32) / (1.0 - p)).contiguous()
+    rm1, rv1, nbt1 = rm0.clone(), rv0.clone(), nbt0.clone()
+    ops.bn_running_update(st, n, 0.1, rm1, rv1, nbt1)
+    sc_ref, sh_ref = ops.bn_fold(Cc, w, b, 1e-5, stats=st, count=n, mask_bc=mask)
+    buf = torch.zeros(2 * Cc, dtype=torch.float64, device="cuda")
+    ops.channel_stats(y, out=buf)                               # adds into the given (zeroed) buffer; float64 atomics: order-dependent
+    assert_close(buf, st, 1e-13, "statistics into a given buffer")     # in the last bits only
+    buf.copy_(st)                                               # the comparison below is on identical statistics
+    rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), nbt0.clone()
+    sc, sh = ops.bn_finish(Cc, w, b, 1e-5, stats=buf, count=n, running_mean=rm2, running_var=rv2, momentum=0.1, num_batches_tracked=nbt2,
+                           mask_u=u, drop_p=p, zero_stats=True)
+    assert torch.equal(sc, sc_ref) and torch.equal(sh, sh_ref)
+    assert torch.equal(rm2, rm1) and torch.equal(rv2, rv1) and int(nbt2) == int(nbt1) == 8
+    assert float(buf.abs().max()) == 0.0
+    sc3, sh3 = ops.bn_finish(Cc, w, b, 1e-5, running_mean=rm1, running_var=rv1)              # eval mode: running statistics, no mask
+    sc4, sh4 = ops.bn_fold(Cc, w, b, 1e-5, running_mean=rm1, running_var=rv1)
+    assert torch.equal(sc3, sc4) and torch.equal(sh3, sh4)
+    sc5, sh5 = ops.bn_finish(Cc, mask_u=u, drop_p=p)                                           # a bare dropout factor
+    assert torch.equal(sc5, mask.reshape(-1)) and float(sh5.abs().max()) == 0.0
+
+
 def _to_blocked(t):
     B, Cc, H, W = t.shape
     return t.view(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, Cc, H, W)
