@@ -899,8 +899,16 @@ def test_baseline_small_configs_inverse_vs_oracle(cfg):
     cond_input = torch.randn(1, 29, side, side, generator=g)
     mean_cache = [0.1 * torch.randn(1, D // 2 ** (n + 1), side, side, generator=g) for n in range(S - 1)]
     low = torch.randn(1, D // 2 ** (S - 1), side, side, generator=g)
-    with torch.no_grad():
-        vols = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache], low=low.cuda(), keep_all=True)
+    from cwfa_amd import ops
+    runs = {}
+    for prec in ("fp32", "split_bf16"):                # the plain fp32 MFMA kernels, and the benchmark's arithmetic
+        ops.set_precision(prec)
+        try:
+            with torch.no_grad():
+                runs[prec] = CWFA.inverse_pass(conv_inn, cond_nets, cond_input.cuda(), [m.cuda() for m in mean_cache], low=low.cuda(),
+                                               keep_all=True)
+        finally:
+            ops.set_precision("fp32")
     cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
     steps = []
     for n, gi in enumerate(conv_inn):
@@ -908,9 +916,10 @@ def test_baseline_small_configs_inverse_vs_oracle(cfg):
         steps.append({"inn": cpu(gi.state_dict()), "omega": cpu(cond_nets[n].state_dict()), "axes": axes})
     with torch.no_grad():
         ref = O.inverse_pass(steps, low, cond_input, mean_cache)
-    assert vols[-1].shape == (1, D, side, side)
-    for i, (a, b) in enumerate(zip(vols, ref)):
-        assert_close(a, b, TOL, f"{what}, level {i}")
+    for prec, vols in runs.items():
+        assert vols[-1].shape == (1, D, side, side)
+        for i, (a, b) in enumerate(zip(vols, ref)):
+            assert_close(a, b, TOL, f"{what}, {prec}, level {i}")
 
 
 @pytest.mark.parametrize("block_type", ["GLOW", "AI1", "RNVP", "GIN"])
