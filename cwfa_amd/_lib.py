@@ -68,6 +68,7 @@ SIGNATURES = {
     "cwfa_subnet_layer_tape_f32": (i, [p, p, p, p, p, p, p, i, i, i, i64, i64, i64, p]),
     "cwfa_subnet_layer_f32": (i, [p, p, p, p, p, p, i, i, i, i64, i64, p]),
     "cwfa_conv3d_1k1_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
+    "cwfa_conv3d_1k1_split_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
     "cwfa_channel_stats_f32": (i, [p, p, i, i, i64, i64, p]),
     "cwfa_channel_stats_blocked8_f32": (i, [p, p, i, i, i64, i64, p]),
     "cwfa_bn_fold_f32": (i, [p, d, p, p, p, p, f, p, i, p, p, i, p]),

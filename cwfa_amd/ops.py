@@ -871,12 +871,21 @@ def conv3d_1k1_backward(x, dy, w1, b1, alpha, w2, want_input_grad=True):
     return dx, dW1, db1, dW2, db2, dalpha
 
 
+SPLIT_CONV3D = True          # (tuning / ablation) False: the fused Conv3d of the condition nets stays on the fp32 MFMA kernel in split / bf16 precision
+
+
 def conv3d_1k1(x, w1, b1, alpha, w2, b2):
+    """Conv3d(1->K) -> PReLU -> Conv3d(K->1) over the (H, W, depth) volume of a [B,D,H,W] tensor (networks.py:221-225,239), one
+    launch; in split / bf16 precision on the bf16 matrix cores (cwfa_conv3d_1k1_split_f32), else fp32 MFMA."""
     L = _lib.lib()
     x = _dev(x, "x").contiguous()
     B, D, H, W = x.shape
     K = w1.shape[0]
     out = torch.empty_like(x)
+    if SPLIT_CONV3D and _split_bf16 >= 2 and K <= 32 and (D + 4) * H * W * 4 < 2 ** 31:
+        check(L.cwfa_conv3d_1k1_split_f32(_p(x), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(alpha)), _p(_dev(w2).contiguous()),
+                                          _p(_dev(b2)), _p(out), B, D, H, W, K, _stream()), "conv3d_1k1_split")
+        return out
     check(L.cwfa_conv3d_1k1_f32(_p(x), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(alpha)), _p(_dev(w2).contiguous()),
                                 _p(_dev(b2)), _p(out), B, D, H, W, K, _stream()), "conv3d_1k1")
     return out

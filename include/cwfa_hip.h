@@ -241,6 +241,12 @@ int cwfa_subnet_layer_tape_f32(const float* x, const float* w3_packed, const flo
  * ---------------------------------------------------------------------------------------------- */
 int cwfa_conv3d_1k1_f32(const float* x, const float* w1, const float* b1, const float* alpha, const float* w2,
                         const float* b2, float* y, int B, int D, int H, int W, int K, void* stream);
+/* The same stage with fp32-equivalent arithmetic on the bf16 matrix cores (three bf16 pieces per operand, six products, fp32
+ * accumulation; "split_products" = 1: plain bf16 operands): both convolutions on v_mfma_f32_16x16x32_bf16, the sum over the
+ * depth taps of the second one taken through the accumulator input while a wave walks the depth axis (csrc/conv3d_split.hip).
+ * Same arguments and semantics as cwfa_conv3d_1k1_f32; K <= 32. */
+int cwfa_conv3d_1k1_split_f32(const float* x, const float* w1, const float* b1, const float* alpha, const float* w2,
+                              const float* b2, float* y, int B, int D, int H, int W, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LRNN pieces (unet.py:72-113,161-195; networks.py:244-262,468-555)

@@ -293,6 +293,61 @@ def test_conv3d_1k1_vs_torch_cpu(cfg):
     assert_close(y, ref, 5e-6)
 
 
+def _conv3d_ref64(x, w1, b1, a, w2, b2):
+    F = torch.nn.functional
+    v = x.double().permute(0, 2, 3, 1).unsqueeze(1)
+    v = F.conv3d(F.prelu(F.conv3d(v, w1.double(), b1.double(), padding=1), a.double()), w2.double(), b2.double(), padding=1)
+    return v[:, 0].permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cfg", [(1, 6, 9, 11, 4, 0.25), (2, 8, 16, 40, 32, 0.25), (1, 12, 8, 32, 32, -0.5), (1, 5, 3, 3, 3, 1.5),
+                                 (1, 7, 20, 70, 32, 0.0), (1, 1, 1, 1, 1, 0.25), (1, 48, 33, 65, 32, 0.25), (2, 3, 29, 31, 17, 1.0)])
+def test_conv3d_1k1_split_is_fp32_accurate(cfg):
+    """networks.py:221-225,239 on the split-bf16 kernel (csrc/conv3d_split.hip): depth ring over chunk borders (D > the depth
+    chunk), ragged tiles, every PReLU slope regime, K < 32 -- against float64 torch under the SAME bound as the fp32 MFMA
+    kernel; then the bf16 configuration (BASELINE.json configs[4]) under its restated bound."""
+    from cwfa_amd import ops
+    B, D, H, W, K, alpha = cfg
+    g = torch.Generator().manual_seed(K + D)
+    x = torch.randn(B, D, H, W, generator=g)
+    w1, b1 = torch.randn(K, 1, 3, 3, 3, generator=g) * 0.3, torch.randn(K, generator=g) * 0.1
+    w2, b2 = torch.randn(1, K, 3, 3, 3, generator=g) * 0.1, torch.randn(1, generator=g)
+    a = torch.tensor([alpha])
+    ref = _conv3d_ref64(x, w1, b1, a, w2, b2)
+    args = [t.cuda() for t in (x, w1, b1, a, w2, b2)]
+    y32 = ops.conv3d_1k1(*args)
+    ops.set_precision("split_bf16")
+    try:
+        y = ops.conv3d_1k1(*args)
+        ops.set_precision("bf16")
+        yb = ops.conv3d_1k1(*args)
+    finally:
+        ops.set_precision("fp32")
+    assert_close(y, ref, 5e-6, "split")
+    assert_close(yb, ref, 2e-2, "bf16")
+    if K * D * H * W > 64:
+        assert not torch.equal(y, y32), "the split mode must run its own kernel"
+        assert not torch.equal(yb, y), "the bf16 mode must differ from the split mode"
+
+
+def test_conv3d_1k1_split_step0_shape_vs_fp32_kernel():
+    """The finest condition net's 3-D stage at its real size (48 x 512 x 512, K = 32): split-bf16 kernel against the fp32 MFMA
+    kernel (itself pinned to float64 above) -- every depth chunk, tile border and the XCD-spread grid."""
+    from cwfa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 48, 512, 512, generator=g).cuda()
+    w1, b1 = (torch.randn(32, 1, 3, 3, 3, generator=g) * 0.3).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn(1, 32, 3, 3, 3, generator=g) * 0.1).cuda(), torch.randn(1, generator=g).cuda()
+    a = torch.tensor([0.25]).cuda()
+    ref = ops.conv3d_1k1(x, w1, b1, a, w2, b2)
+    ops.set_precision("split_bf16")
+    try:
+        y = ops.conv3d_1k1(x, w1, b1, a, w2, b2)
+    finally:
+        ops.set_precision("fp32")
+    assert_close(y, ref, 5e-6)
+
+
 # ------------------------------------------------------------------------------------------------ blocks
 def _block(bname, cl, fx):
     from cwfa_amd import networks as N
