@@ -42,6 +42,27 @@ __device__ __forceinline__ float cwfa_wave_sum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result valid in all 16: quad xor 1, quad xor 2, mirror of the
+// half row, mirror of the row -- four VALU instructions, no LDS
+__device__ __forceinline__ float cwfa_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// 16-byte buffer store with an SGPR offset.  gfx950: the store keeps reading its data registers after issue, also in this
+// addressing form, which LLVM's hazard rule exempts ("only if soffset is not a register"): a VALU write into the tuple right
+// behind it corrupted the stored data.  EVERY 16-byte buffer store of the library goes through
+// this helper, which carries the wait states and keeps the scheduler from moving anything across.
+typedef unsigned cwfa_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cwfa_buffer_store_b128(cwfa_u32x4 data, __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // block-wide sum of doubles (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
 __device__ __forceinline__ double cwfa_block_sum(double v, double* lds /* >= 16 doubles */) {
     v = cwfa_wave_sum(v);

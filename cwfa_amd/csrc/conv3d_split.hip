@@ -18,6 +18,7 @@
 // ring: slab d' + 2 is written while hidden slab d' is computed, slab d' + 3 is in flight in registers.  One barrier per slab.
 #include "common.h"
 
+#include <stdlib.h>
 #include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -25,6 +26,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef C3S_SGB
+#define C3S_SGB 0
+#endif
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
 
@@ -317,6 +322,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
                     ring[S1][col] = mfma6<SIX>(ring[S1][col], A2[1], B2);
                     ring[S2][col] = mfma6<SIX>(ring[S2][col], A2[2], B2);
                 }
+#if C3S_SGB > 0
+                // scheduling pipeline over the four columns: one MFMA, then C3S_SGB vector instructions, ...
+#pragma unroll
+                for (int i = 0; i < NCOL * (SIX ? 30 : 5); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, C3S_SGB, 0);
+                }
+#endif
             } else {
 #pragma unroll
                 for (int col = 0; col < NCOL; ++col) ring[S0][col] = zero4;
@@ -426,6 +439,9 @@ extern "C" int cwfa_conv3d_1k1_split_f32(const float* x, const float* w1, const 
             DC = dc;
         }
     }
+#ifdef C3S_DC_ENV
+    if (const char* e = getenv("CWFA_C3S_DC")) DC = atoi(e) > 0 ? (atoi(e) < D ? atoi(e) : D) : DC;
+#endif
     const int chunks = (D + DC - 1) / DC;
     CWFA_REQUIRE(chunks <= 65535, CWFA_E_SHAPE, "cwfa_conv3d_1k1_split_f32: grid too large");
     P3 p{x, w1, b1, alpha, w2, b2, y, D, H, W, K, tw, DC};

@@ -483,9 +483,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         return;
     }
     const bool outb = p.o.out_blocked8 != 0;           // (uniform) y channel-blocked [Cout/8][H][W][8]: the lane's four channels = 16 bytes
+    // cwfa_conv_opts.out_stats: per-channel (sum, sum of squares) of the output for the BatchNorm that follows (unet.py:99-107):
+    // lane sums over its n-tiles, 16-lane DPP sums (pixels of a row), the block's two row halves through LDS (the operand
+    // buffers are dead), then one float64 atomic pair per channel and block
+    const bool want_stats = ACT1 != EPI_RUNTIME && p.o.out_stats != nullptr;
+    float* red = reinterpret_cast<float*>(lds);        // [wn 2][CT][2]
 #pragma unroll
     for (int mt = 0; mt < MPW; ++mt) {
         float bias[4];
+        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
@@ -498,10 +504,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o4[r] = act_of<ACT1>(acc[mt][nt][r] + bias[r], alpha);
                     const unsigned pb = (row < p.H && col < p.W) ? (unsigned)(((g >> 1) * HW + row * p.W + col) * 32 + (g & 1) * 16) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o4), ry, pb,
-                                                           (cwave + mt * 16) * plane, 0);
-                    asm volatile("s_nop 1");          // store-data hazard of 16-byte buffer stores with an SGPR offset (conv_split_layer.hip)
-                    FENCE();
+                    cwfa_buffer_store_b128(__builtin_bit_cast(cwfa_u32x4, o4), ry, pb, (cwave + mt * 16) * plane);   // (+ wait states: common.h)
                     continue;
                 }
             }
@@ -516,10 +519,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                     v = cwfa_act(v, p.o.act2, alpha);
                 } else {
                     v = act_of<ACT1>(v, alpha);
+                    if (want_stats) {
+                        const float vm = po != OOB ? v : 0.f;
+                        st1[r] += vm;
+                        st2[r] += vm * vm;
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, po, soff, 0);
             }
             FENCE();                 // keep the results from being staged in registers all at once
+        }
+        if constexpr (ACT1 != EPI_RUNTIME) {
+            if (want_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = cwfa_row16_sum(st1[r]), a2 = cwfa_row16_sum(st2[r]);
+                    if (c16 == 0) {
+                        const int ch = (wm * MPW + mt) * 16 + 4 * g + r;
+                        red[(wn * CT + ch) * 2] = a1;
+                        red[(wn * CT + ch) * 2 + 1] = a2;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (ACT1 != EPI_RUNTIME) {
+        if (want_stats) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int ch = ct * CT + tid;
+            if (tid < CT && ch < p.Cout) {
+                const double s1 = (double)red[tid * 2] + (double)red[(CT + tid) * 2];
+                const double s2 = (double)red[tid * 2 + 1] + (double)red[(CT + tid) * 2 + 1];
+                atomicAdd(&p.o.out_stats[2 * ch], s1);
+                atomicAdd(&p.o.out_stats[2 * ch + 1], s2);
+            }
         }
     }
 }
@@ -698,6 +731,9 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
                                        (p.o.act == CWFA_ACT_NONE || p.o.act == CWFA_ACT_PRELU)),
                  CWFA_E_ALIGN, "cwfa_conv3x3_split_f32: blocked output needs Cout %% 8 == 0, 16-byte alignment and a bias / PReLU epilogue");
     CWFA_REQUIRE(!(p.o.in_scale && !p.o.in_shift), CWFA_E_INVAL, "cwfa_conv3x3_split_f32: in_scale without in_shift");
+    CWFA_REQUIRE(!p.o.out_stats || (!p.o.out_blocked8 && !p.o.residual && p.o.act2 == CWFA_ACT_NONE &&
+                                    (p.o.act == CWFA_ACT_NONE || p.o.act == CWFA_ACT_PRELU)),
+                 CWFA_E_INVAL, "cwfa_conv3x3_split_f32: out_stats needs an NCHW output and a bias / PReLU epilogue");
     CWFA_REQUIRE(p.o.act >= 0 && p.o.act <= CWFA_ACT_RELU && p.o.act2 >= 0 && p.o.act2 <= CWFA_ACT_RELU, CWFA_E_INVAL,
                  "cwfa_conv3x3_split_f32: bad activation");
     CWFA_REQUIRE(!((p.o.act == CWFA_ACT_PRELU || p.o.act2 == CWFA_ACT_PRELU) && !p.o.prelu_alpha), CWFA_E_INVAL,
@@ -748,7 +784,7 @@ extern "C" int cwfa_conv7x7_split_f32(const float* x, const void* w_packed, floa
     p.x = x; p.wp = w_packed; p.y = y;
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.x_bs = x_bs; p.y_bs = y_bs;
     if (opts) p.o = *opts;
-    CWFA_REQUIRE(!p.o.upshuffle2 && !p.o.in_cat && !p.o.in_scale && !p.o.in_add && !p.o.in_blocked8 && !p.o.out_blocked8 && !p.o.residual &&
+    CWFA_REQUIRE(!p.o.upshuffle2 && !p.o.in_cat && !p.o.in_scale && !p.o.in_add && !p.o.in_blocked8 && !p.o.out_blocked8 && !p.o.residual && !p.o.out_stats &&
                      p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE,
                  CWFA_E_INVAL, "cwfa_conv7x7_split_f32: bias-only epilogue, no load-side prologue, NCHW maps");
     p.nchunks = (Cin + 15) / 16;

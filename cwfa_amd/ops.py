@@ -391,10 +391,17 @@ def pack_conv_weight_cat(w, c1):
     return pc
 
 
+def conv_writes_stats(pc, act=None, residual=None, act2=None, out_blocked=False):
+    """True when conv2d(..., out_stats=) is available for this bank / epilogue: the split-bf16 3x3 kernel with an NCHW output and
+    a bias / PReLU epilogue takes the per-channel (sum, sum of squares) of its output from the accumulators."""
+    return bool(pc.split and pc.ks == 3 and act in (None, "prelu") and residual is None and act2 is None and not out_blocked)
+
+
 def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=None, in_scale=None, in_shift=None,
-           in_add=None, out=None, in_blocked=False, out_blocked=False, cat=None):
+           in_add=None, out=None, in_blocked=False, out_blocked=False, cat=None, out_stats=None):
     """y = act2(act(conv(x') + bias) + residual), x' = x*in_scale[c] + in_shift[c] + in_add.  Transposed banks
-    (ConvTranspose2d k2 s2) write the pixel-shuffled [B,Co,2H,2W] output."""
+    (ConvTranspose2d k2 s2) write the pixel-shuffled [B,Co,2H,2W] output.  ``out_stats`` (float64 [2*Cout], see
+    conv_writes_stats): the launch adds (sum y, sum y^2) per channel -- the statistics of a BatchNorm behind the convolution."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cin, H, W = x.shape
@@ -457,6 +464,12 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
             raise ValueError("conv2d: channel-blocked output is written by the split-bf16 3x3 kernel (bias / PReLU) and by the "
                              "direct 1x1 kernel with 40..64 output channels only")
         o.out_blocked8 = 1
+    if out_stats is not None:
+        if not conv_writes_stats(pc, act, residual, act2, out_blocked):
+            raise ValueError("conv2d: out_stats needs the split-bf16 3x3 kernel with an NCHW output and a bias / PReLU epilogue")
+        if out_stats.dtype != torch.float64 or out_stats.numel() != 2 * pc.cout or not out_stats.is_cuda:
+            raise ValueError("conv2d: out_stats must be a float64 [2*Cout] tensor on the HIP device")
+        o.out_stats = out_stats.data_ptr()
     rec = conv_event_sink
     if rec is not None:                    # bench.py: HIP events around selected launches, on the launch stream
         # the last field names the kernel instantiation the C side dispatches to (prologue / epilogue variant)

@@ -52,18 +52,36 @@ class _Drop:
         return ((self.u >= self.p).to(torch.float32) / (1.0 - self.p)).contiguous()
 
 
-def _bn_affine(bn, y, drop=None, blocked=False):
+STATS_IN_EPILOGUE = True      # (tuning / ablation) False: train-mode BatchNorm statistics always by a separate pass (ops.channel_stats)
+
+
+def _bn_batch_stats(bn):
+    return bn.training or not bn.track_running_stats
+
+
+def _bn_stats_buffer(bn, device):
+    """The layer's own float64 [2C] statistics buffer, zeroed (bn_finish clears it again after use; an exception in between
+    leaves the dirty flag set and the buffer is rebuilt).  Accumulated on the CURRENT stream only: two forwards of the same
+    module on different streams must not overlap."""
+    st = getattr(bn, "_cwfa_stats", None)
+    if st is None or st.device != device or getattr(bn, "_cwfa_stats_dirty", False):
+        st = bn._cwfa_stats = torch.zeros(2 * bn.num_features, dtype=torch.float64, device=device)
+    bn._cwfa_stats_dirty = True
+    return st
+
+
+def _bn_affine(bn, y, drop=None, blocked=False, stats=None):
     """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output; ``blocked``: channel-blocked map), times the
-    pending dropout factor ``drop`` (a _Drop or a ready [B,C] mask).  Train mode: one statistics pass into the layer's own
-    (kept zeroed) float64 buffer, then ONE launch for fold + running-buffer bookkeeping + dropout factor + re-zeroing."""
+    pending dropout factor ``drop`` (a _Drop or a ready [B,C] mask).  Train mode: the statistics come from the producing
+    convolution's epilogue (``stats``: the buffer it added into, ops.conv2d(out_stats=)) or from one pass over ``y`` into the
+    layer's own (kept zeroed) float64 buffer; then ONE launch for fold + running-buffer bookkeeping + dropout factor + re-zeroing."""
     C = bn.num_features
     mu, mb, p = (drop.u, None, drop.p) if isinstance(drop, _Drop) else (None, drop, 0.0)
-    if bn.training or not bn.track_running_stats:
-        st = getattr(bn, "_cwfa_stats", None)
-        if st is None or st.device != y.device or getattr(bn, "_cwfa_stats_dirty", False):
-            st = bn._cwfa_stats = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
-        bn._cwfa_stats_dirty = True                          # (an exception before bn_finish leaves it set: the buffer is rebuilt)
-        ops.channel_stats(y, blocked=blocked, out=st)
+    if _bn_batch_stats(bn):
+        st = stats
+        if st is None:
+            st = _bn_stats_buffer(bn, y.device)
+            ops.channel_stats(y, blocked=blocked, out=st)
         n = y.numel() // C
         track = bn.track_running_stats and bn.momentum is not None       # buffer bookkeeping, as nn.BatchNorm2d does
         out = ops.bn_finish(C, bn.weight, bn.bias, bn.eps, stats=st, count=float(n), running_mean=bn.running_mean if track else None,
@@ -154,13 +172,19 @@ class UNetConvBlock(nn.Module):
                 # kernel (x1.2 on the 512 / 1024-channel layers) only pays off without it -- the pass costs 2-7 %
                 x = ops.plane_affine(x, sc, sh, add=add)
                 sc = sh = add = None
+            # train-mode BatchNorm behind the convolution: its statistics come out of the convolution's epilogue where the
+            # kernel can do that (split-bf16 3x3, NCHW output)
+            st = None
+            if (STATS_IN_EPILOGUE and bn is not None and _bn_batch_stats(bn)
+                    and ops.conv_writes_stats(packs[li], kind, None, None, out_blocked)):
+                st = _bn_stats_buffer(bn, x.device)
             x = ops.conv2d(x, packs[li], bias=conv.bias, act=kind, prelu_alpha=alpha, in_scale=sc,
-                           in_shift=sh, in_add=add, in_blocked=blocked, out_blocked=out_blocked)
+                           in_shift=sh, in_add=add, in_blocked=blocked, out_blocked=out_blocked, out_stats=st)
             blocked = out_blocked
             last = li == len(layers) - 1
             m = out_mask if last else None
             if bn is not None:
-                aff = _bn_affine(bn, x, m, blocked=blocked)
+                aff = _bn_affine(bn, x, m, blocked=blocked, stats=st)
             elif m is not None:
                 aff = _drop_affine(x.shape[1], m)
             else:

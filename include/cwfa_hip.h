@@ -215,6 +215,10 @@ typedef struct {
                                  channels(in_cat) with zero columns in [in_cat_c1, in_cat_from), in_cat_from % 16 == 0 */
     int64_t in_cat_bs;
     int in_cat_from, in_cat_c1;
+    double* out_stats;        /* cwfa_conv3x3_split_f32 only (NCHW output, bias / PReLU epilogue): nullable [2*Cout]; the
+                                 launch ADDS (sum y, sum y^2) of its output over (B,H,W) per channel -- the train-mode
+                                 BatchNorm statistics of the layer that follows the convolution (unet.py:99-107), taken
+                                 from the accumulators instead of a second pass over y (cwfa_channel_stats_f32)       */
 } cwfa_conv_opts;
 
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,

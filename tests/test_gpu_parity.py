@@ -1319,6 +1319,40 @@ def test_conv1x1_two_source_input_equals_the_concatenation(cfg):
         ops.conv2d(x2, pc, bias=bias, cat=x)
 
 
+@pytest.mark.parametrize("cfg", [(1, 64, 256, 64, 64, "prelu"), (2, 24, 100, 19, 45, "prelu"), (2, 40, 40, 33, 31, None), (1, 16, 300, 8, 32, "prelu"),
+                                 (1, 64, 64, 40, 64, None)])
+def test_conv_epilogue_statistics_equal_a_pass_over_the_output(cfg):
+    """cwfa_conv_opts.out_stats (unet.py:99-107: conv -> PReLU -> train-mode BatchNorm): the (sum, sum of squares) the split-bf16
+    3x3 kernel takes from its accumulators against ops.channel_stats of the tensor it wrote -- every tiling (64 / 128 / 256
+    output channels, 16-row tiles), ragged image borders, channels past Cout, batch > 1, accumulation into a used buffer."""
+    from cwfa_amd import ops
+    B, Cin, Cout, H, W, act = cfg
+    g = torch.Generator().manual_seed(Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    a = torch.tensor([0.2]).cuda()
+    ops.set_precision("split_bf16")
+    try:
+        pc = ops.pack_conv_weight(w)
+        assert ops.conv_writes_stats(pc, act)
+        st = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+        y = ops.conv2d(x, pc, bias=b, act=act, prelu_alpha=a if act else None, out_stats=st)
+        y0 = ops.conv2d(x, pc, bias=b, act=act, prelu_alpha=a if act else None)
+        ops.conv2d(x, pc, bias=b, act=act, prelu_alpha=a if act else None, out_stats=st)      # adds: twice the sums
+    finally:
+        ops.set_precision("fp32")
+    assert torch.equal(y, y0)
+    ref = ops.channel_stats(y).cpu()
+    ref64 = torch.stack([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))], 1).reshape(-1).cpu()
+    scale = ref64.view(-1, 2)[:, 1].max().sqrt() * (B * H * W) ** 0.5     # |sum| <= sqrt(n * sumsq)
+    assert float((ref - ref64).abs().max()) <= 1e-6 * float(scale)
+    assert float((st.cpu() / 2 - ref64).view(-1, 2)[:, 0].abs().max()) <= 2e-6 * float(scale)
+    assert float(((st.cpu() / 2 - ref64).view(-1, 2)[:, 1] / ref64.view(-1, 2)[:, 1]).abs().max()) <= 2e-6
+    with pytest.raises(ValueError):
+        ops.conv2d(x, ops.pack_conv_weight(w), bias=b, out_stats=st)          # fp32 precision: no such epilogue
+
+
 @pytest.mark.parametrize("cfg", [(1, 64, 64, 40, 70), (2, 40, 33, 19, 33), (1, 64, 64, 128, 128), (1, 32, 64, 8, 32)])
 def test_split_bf16_7x7_is_fp32_accurate(cfg):
     """cwfa_conv7x7_split_f32 (the split 3x3 kernel with a 3-pixel halo and 49 taps: the ConvNeXt convolution, networks.py:488)
