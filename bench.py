@@ -161,6 +161,26 @@ def roofline_of(fam, t_ms, n, flops, shapes, products, share=None, all_conv_ms=N
     return r
 
 
+def launch_command(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it is started without a launcher: the same launch the
+    driver uses (one process per GPU, rendezvous on 127.0.0.1 -- the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(launch_command(n, argv), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,11 +215,15 @@ def main():
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher (one rank per GPU over RCCL) BEFORE anything touches the GPU in
+        # this process, forward the ranks' output (rank 0 prints the JSON line) and exit with their status
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
     import torch.distributed as dist
     # rehearsal switch (not used by the driver): several ranks on ONE card over gloo, to exercise the N > 1 control flow
     # on a single-GPU box (RCCL refuses two ranks on one device)
@@ -319,6 +343,13 @@ def main():
             "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
+            # what `value` is, for a reader of `metric` / `value` alone (the metric string is BASELINE.json's and says "fp32")
+            "value_label": {"split": "fp32-equivalent (bf16 x 3 split, six products per fp32 product, fp32 accumulate); plain fp32 MFMA: fp32_mfma",
+                            "fp32": "plain fp32 MFMA (v_mfma_f32_32x32x2_f32 / Winograd)",
+                            "bf16": "bf16 conv operands (BASELINE.json configs[4]), NOT the fp32 headline"}[a.precision],
+            "multi_gpu": ("this line is N = 1; the 1/2/4/8-GPU half of the metric and the RCCL NLL all-reduce are UNMEASURED on hardware "
+                          "so far (builders cannot launch multi-GPU runs; `python bench.py --gpus N` starts its own ranks)") if world == 1 else
+                         f"{world} ranks, one per GPU, {'gloo on ONE card (rehearsal)' if rehearse else 'RCCL'}; see forward_nll.nll_check",
             "config": {"workload": f"{a.side}x{a.side}x{a.depths} volume, 4-scale CWFA ({a.block_type} blocks, 64 ch) + "
                                    f"{'LRNN' if not a.no_lrnn else 'synthetic low-res (NO LRNN: diagnostic)'} inverse, z=0, "
                                    f"batch {B}/GPU, random-init weights (BASELINE.json configs[2])",

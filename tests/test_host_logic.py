@@ -235,3 +235,45 @@ def test_plan_lowering_of_actnorm_and_mixed_graphs_on_cpu():
     except TypeError:
         return                                             # this HaarTransform1D takes no rebalance argument: nothing to check
     assert g._plan is None
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launcher plumbing
+def test_bench_self_launch_plumbing(monkeypatch, tmp_path):
+    """`python bench.py --gpus N` without a launcher must start the driver's own launch (torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1) BEFORE touching the GPU, forward the arguments unchanged and return the ranks' status."""
+    import importlib
+    import subprocess
+    import sys as _sys
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "7", "--warmup", "2"], port=29512)
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert isinstance(int(bench.launch_command(2, [])[bench.launch_command(2, []).index("--master-port") + 1]), int)   # a free port is picked
+
+    seen = {}
+
+    def fake_run(c, env=None, **kw):
+        seen["cmd"], seen["env"] = c, env
+        return subprocess.CompletedProcess(c, 3)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 3                                  # the ranks' status is the launcher's status
+    else:
+        raise AssertionError("main() must exit through the launcher")
+    assert seen["cmd"][-4:] == ["--gpus", "2", "--steps", "1"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher with a different world size: refuse, never re-launch
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    seen.clear()
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert "must agree" in str(e.code) and not seen
