@@ -210,8 +210,6 @@ def main():
     ap.add_argument("--no-split7x7", action="store_true", help="(ablation) the ConvNeXt 7x7 convolution on the fp32 MFMA kernel")
     ap.add_argument("--no-rows16", action="store_true", help="(ablation) 8-row tiles for the 64-channel tiling of the split 3x3 kernel")
     ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
-    ap.add_argument("--group-layers", action="store_true", help="(ablation) the k-th residual layers of the five independent sub-networks "
-                    "of a CAT step in one grouped launch instead of one launch per sub-network and layer (measured: no gain)")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -255,8 +253,6 @@ def main():
         global ROWS16
         ROWS16 = False
         ops.set_option("split3x3_rows16", 0)
-    if a.group_layers:
-        ops.GROUP_LAYERS = True
     if a.split3x3_min is not None:
         ops.SPLIT_3X3_MIN_COUT = a.split3x3_min
     PREC = {"split": "split_bf16", "fp32": "fp32", "bf16": "bf16"}

@@ -207,7 +207,13 @@ class GraphINN(InvertibleModule):
         if self._plan is not None and not intermediate_outputs and not self._plan.needs_walk():
             return self._plan.run(x_or_z, c, rev, sumsq, jac)
         if any(t is None for t in x_or_z):
-            raise ValueError("None (an all-zero latent) is only understood by fused step plans")
+            # None = an all-zero latent (the default T = 0 inverse pass, CWFA.py:54-55).  The fused plans never read it; the node
+            # walk (any other graph, or a plan that first has to initialise an ActNorm from this batch) needs the tensor
+            ref = next((t for t in list(x_or_z) + c if t is not None), None)
+            if not rev or ref is None:
+                raise ValueError("None (an all-zero latent) is only understood for rev=True with at least one tensor input")
+            x_or_z = tuple(t if t is not None else torch.zeros((ref.shape[0],) + tuple(shp), dtype=ref.dtype, device=ref.device)
+                           for t, shp in zip(x_or_z, self.global_out_shapes))
         return self._walk(x_or_z, c, rev, jac, intermediate_outputs)
 
     def _walk(self, x_or_z, c, rev, jac, intermediate_outputs):
@@ -337,17 +343,6 @@ class _CatStepPlan:
         -> (s_raw, t, t_neg_div_sqrt2) replaces the block's own sub-network call (the training path keeps a tape)."""
         stages, pending = [], None
         seq = list(reversed(self.chain)) if rev else self.chain
-        if coefficients is None:
-            # the blocks' sub-networks are independent of each other (their inputs are the conditions): layer by layer in
-            # grouped launches where that form applies (networks.grouped_affine_parts)
-            cats = [obj for kind, obj in seq if kind == "cat"]
-            grouped = None
-            if len(cats) > 1 and all(hasattr(n.module.subnet, "affine_parts") for n in cats):
-                from ...networks import grouped_affine_parts
-                grouped = grouped_affine_parts([(n.module.subnet, [cond_of[cn] for cn in n.conditions], n.module.channels) for n in cats])
-            if grouped is not None:
-                pre = {id(n.module): r for n, r in zip(cats, grouped)}
-                coefficients = lambda module, c: pre[id(module)]      # noqa: E731
         for kind, obj in seq:
             if kind == "perm":
                 if pending is not None:                                 # two permutations in a row: identity affine

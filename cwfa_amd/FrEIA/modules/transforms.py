@@ -285,7 +285,7 @@ class ActNorm(InvertibleModule):
         """This module as a stage of a fused step chain (GraphINN plan lowering): s = scale_c, t = bias_c, no clamp --
         ``y = exp(s) x + t`` / ``(x - t) exp(-s)`` with log-det +-sum s.  The chain kernels read s, t per element, so the two
         per-channel vectors are broadcast once per parameter version into [1,C,H,W] tables shared by the whole batch."""
-        key = (self.scale._version, self.bias._version, self.scale.data_ptr(), self.bias.data_ptr())
+        key = (self.scale._version, self.bias._version, self.scale.data_ptr(), self.bias.data_ptr(), ops.pack_epoch())
         if getattr(self, "_chain_tabs", None) is None or self._chain_tabs[0] != key:
             Cc, H, W = self.dims_in
             s_tab = self.scale.detach().reshape(1, Cc, 1, 1).expand(1, Cc, H, W).contiguous()

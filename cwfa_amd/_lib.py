@@ -70,7 +70,6 @@ SIGNATURES = {
     "cwfa_conv3d_1k1_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
     "cwfa_conv3d_1k1_split_f32": (i, [p, p, p, p, p, p, p, i, i, i, i, i, p]),
     "cwfa_channel_stats_f32": (i, [p, p, i, i, i64, i64, p]),
-    "cwfa_channel_stats_blocked8_f32": (i, [p, p, i, i, i64, i64, p]),
     "cwfa_bn_fold_f32": (i, [p, d, p, p, p, p, f, p, i, p, p, i, p]),
     "cwfa_maxpool_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, p]),
     "cwfa_sample_stats_f32": (i, [p, p, i, i64, p]),
@@ -114,8 +113,6 @@ SIGNATURES = {
     "cwfa_subnet_layer_split_packed_bytes": (i64, []),
     "cwfa_subnet_layer_split_pack_f32": (i, [p, p, p, p]),
     "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, i, p]),
-    "cwfa_subnet_layer_split_max_problems": (i, []),
-    "cwfa_subnet_layer_split_group_f32": (i, [p, p, p, p, p, i, i, i, i, i64, i64, i, p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }
 del i, i64, f, d, p

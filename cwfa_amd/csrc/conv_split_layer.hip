@@ -521,16 +521,6 @@ extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, c
     return layer_launch(x, packed, b3, b1, y, B, H, W, x_bs, y_bs, layout, 1, B > 0 ? B : 1, stream);
 }
 
-extern "C" int cwfa_subnet_layer_split_max_problems(void) { return MAXP; }
-
-extern "C" int cwfa_subnet_layer_split_group_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int nprob,
-                                                 int samples_per_problem, int H, int W, int64_t x_bs, int64_t y_bs, int layout,
-                                                 void* stream) {
-    CWFA_REQUIRE(nprob >= 1 && nprob <= MAXP && samples_per_problem >= 1, CWFA_E_SHAPE,
-                 "cwfa_subnet_layer_split_group_f32: 1 <= nprob <= %d, samples_per_problem >= 1", MAXP);
-    return layer_launch(x, packed, b3, b1, y, nprob * samples_per_problem, H, W, x_bs, y_bs, layout, nprob, samples_per_problem, stream);
-}
-
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
                         int64_t y_bs, int layout, int nprob, int spp, void* stream) {
     CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);

@@ -70,49 +70,6 @@ extern "C" int cwfa_channel_stats_f32(const float* x, double* stats, int B, int 
     return CWFA_OK;
 }
 
-// channel-blocked map [C/8][HW][8]: grid (splits, C/8, B); a thread adds the 8 channels of its pixels (two 16-byte loads)
-__global__ __launch_bounds__(256) void channel_stats_blocked8_kernel(const float* __restrict__ x, double* __restrict__ stats, int64_t HW,
-                                                                     int64_t x_bs) {
-    __shared__ double red[16];
-    const int cb = blockIdx.y;
-    const cs_f4* p4 = reinterpret_cast<const cs_f4*>(x + (int64_t)blockIdx.z * x_bs + (int64_t)cb * HW * 8);
-    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per < HW ? (int64_t)blockIdx.x * per : HW, hi = lo + per < HW ? lo + per : HW;
-    double s[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const cs_f4 a = p4[2 * i], b = p4[2 * i + 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] += a[j];
-            q[j] += (double)a[j] * a[j];
-            s[4 + j] += b[j];
-            q[4 + j] += (double)b[j] * b[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const double sj = cwfa_block_sum(s[j], red), qj = cwfa_block_sum(q[j], red);
-        if (threadIdx.x == 0) {
-            atomicAdd(&stats[2 * (cb * 8 + j)], sj);
-            atomicAdd(&stats[2 * (cb * 8 + j) + 1], qj);
-        }
-    }
-}
-
-extern "C" int cwfa_channel_stats_blocked8_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream) {
-    CWFA_REQUIRE(x && stats, CWFA_E_INVAL, "cwfa_channel_stats_blocked8_f32: null pointer");
-    CWFA_REQUIRE(B >= 0 && C >= 0 && HW >= 0 && C % 8 == 0 && C / 8 <= 65535 && B <= 65535, CWFA_E_SHAPE, "cwfa_channel_stats_blocked8_f32: bad shape");
-    CWFA_REQUIRE(cwfa_aligned16(x) && (x_bs & 3) == 0, CWFA_E_ALIGN, "cwfa_channel_stats_blocked8_f32: x must be 16-byte aligned");
-    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
-    int splits = (int)((HW + 256 * 8 - 1) / (256 * 8));            // >= 8 pixels (64 elements) per thread
-    if (splits < 1) splits = 1;
-    if (splits > 128) splits = 128;
-    hipLaunchKernelGGL(channel_stats_blocked8_kernel, dim3(splits, C / 8, B), dim3(256), 0, (hipStream_t)stream, x, stats, HW, x_bs);
-    CWFA_LAUNCH_CHECK("cwfa_channel_stats_blocked8_f32");
-    return CWFA_OK;
-}
 
 __global__ void bn_fold_kernel(const double* __restrict__ stats, double count, const float* __restrict__ rm,
                                const float* __restrict__ rv, const float* __restrict__ w, const float* __restrict__ bsh,

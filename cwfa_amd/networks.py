@@ -41,6 +41,7 @@ _CONVS = (nn.Conv2d, nn.Conv3d, nn.Linear)
 # --------------------------------------------------------------------------------------------------- initialisers
 def subnet_initialization(m):
     """Kaiming-uniform weights, bias x 0.1.  networks.py:19-27."""
+    ops.invalidate_packs()          # `.data` edits below do not bump the version counters the pack caches are keyed on
     if isinstance(m, _CONVS):
         nn.init.kaiming_uniform_(m.weight.data)
         if m.bias is not None:
@@ -49,6 +50,7 @@ def subnet_initialization(m):
 
 def subnet_initialization_small(m):
     """Xavier-uniform (gain 0.01) weights, bias x 0.01.  networks.py:29-38."""
+    ops.invalidate_packs()          # `.data` edits below do not bump the version counters the pack caches are keyed on
     if isinstance(m, _CONVS):
         nn.init.xavier_uniform_(m.weight.data, 0.01)
         if m.bias is not None:
@@ -57,6 +59,7 @@ def subnet_initialization_small(m):
 
 def zero_initialization(m):
     """networks.py:40-49."""
+    ops.invalidate_packs()          # `.data` edits below do not bump the version counters the pack caches are keyed on
     if isinstance(m, _CONVS):
         nn.init.constant_(m.weight.data, 0.0)
         if m.bias is not None:
@@ -65,6 +68,7 @@ def zero_initialization(m):
 
 def subnet_initialization_positive(m):
     """|Xavier-uniform (gain 0.1)| weights, bias x 0.1.  networks.py:51-62."""
+    ops.invalidate_packs()          # `.data` edits below do not bump the version counters the pack caches are keyed on
     if isinstance(m, _CONVS):
         nn.init.xavier_uniform_(m.weight.data, 0.1)
         m.weight.data = m.weight.data.abs()
@@ -75,6 +79,7 @@ def subnet_initialization_positive(m):
 def reset_ActNorm(network, n_to_reset=50):
     """Re-arm the data-dependent init of the first ``n_to_reset`` ActNorm layers.  networks.py:137-151."""
     n = 0
+    ops.invalidate_packs()
     for mod in next(network.named_children())[1]:
         if isinstance(mod, Fm.ActNorm):
             mod.init_on_next_batch = True
@@ -253,68 +258,6 @@ class wavelet_flow_subnetwork(nn.Module):
             C.c_void_p(zero.data_ptr()), 1, None, None, B, mean.shape[1], H * W, mbs, out.shape[1] * H * W,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "subnet_first tail")
         return out
-
-
-_group_cache = {}
-
-
-def grouped_affine_parts(jobs):
-    """``[net.affine_parts(parts, n_s) for net, parts, n_s in jobs]`` for up to five INDEPENDENT sub-networks of the same
-    shape (the blocks of a CAT step: their inputs are the conditions, coupling_layers.py:475-500) with the k-th residual
-    layers of all of them in ONE persistent launch (ops.subnet_layer_group): at batch 1 a layer launch is two tiles per CU
-    and its un-overlapped first fill / last epilogue cost ~10 %.  Returns None when the grouped form does not apply (then the
-    caller runs the sub-networks one by one)."""
-    if not ops.GROUP_LAYERS or not (2 <= len(jobs) <= 5) or ops._split_bf16 < 2:
-        return None
-    plan = []
-    for net, parts, n_s in jobs:
-        if not isinstance(net, wavelet_flow_subnetwork) or net.conv_type is not nn.Conv2d or net.n_ch != 64:
-            return None
-        if net.normal:
-            u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
-            plan.append((net, u, net.block12, net.block72[1], None, n_s))
-        else:
-            n = net.c_in // 2
-            if not (len(parts) == 2 and parts[1].shape[1] == n and net.c_out // 2 == n_s):
-                return None
-            plan.append((net, parts[1], net.block1, net.block7[1], parts[0], n_s))
-    B, _, H, W = plan[0][1].shape
-    if any(tuple(u.shape[0:1] + u.shape[2:]) != (B, H, W) for _, u, *_ in plan) or 64 * H * W * 4 >= 2 ** 31:
-        return None
-    P = len(plan)
-    for net, _, cin, _, _, _ in plan:
-        pc = net._packed.get(cin)
-        if pc.split or pc.ks != 1 or pc.cout != 64 or any(blk[0].bias is None or blk[2].bias is None
-                                                          for blk in (net.block2, net.block4, net.block6)):
-            return None
-    # packed images / biases of the k-th layers, back to back (rebuilt when a weight, bias or packing option changes)
-    convs = [[(getattr(net, name)[0], getattr(net, name)[2]) for net, *_ in plan] for name in ("block2", "block4", "block6")]
-    key = tuple((id(c3), c3.weight._version, c3.weight.data_ptr(), c1.weight._version, c1.weight.data_ptr(), c3.bias._version,
-                 c1.bias._version) for layer in convs for c3, c1 in layer) + (ops.pack_epoch(),)
-    hit = _group_cache.get(key[0][0])
-    if hit is None or hit[0] != key:
-        banks = []
-        for layer, name in zip(convs, ("block2", "block4", "block6")):
-            imgs = [net._split3(c3, c1).packed for (net, *_), (c3, c1) in zip(plan, layer)]
-            banks.append((torch.cat(imgs), torch.stack([c3.bias.detach() for c3, _ in layer]).contiguous(),
-                          torch.stack([c1.bias.detach() for _, c1 in layer]).contiguous()))
-        hit = _group_cache[key[0][0]] = (key, banks)
-    banks = hit[1]
-    pcs_out = [net._packed.get(cout) for net, _, _, cout, _, _ in plan]
-    last_blocked = ops.BLOCKED_MAPS and all(pc.split and pc.ks == 3 for pc in pcs_out)
-    buf = torch.empty((P * B, 64, H, W), dtype=torch.float32, device=plan[0][1].device)
-    for i, (net, u, cin, _, _, _) in enumerate(plan):
-        ops.conv2d(u, net._packed.get(cin), bias=cin.bias, out=buf[i * B:(i + 1) * B], out_blocked=ops.BLOCKED_MAPS)
-    blocked = ops.BLOCKED_MAPS
-    for k, (packed, b3, b1) in enumerate(banks):
-        out_blocked = ops.BLOCKED_MAPS and (k < 2 or last_blocked)
-        buf = ops.subnet_layer_group(buf, packed, b3, b1, P, layout=int(blocked) | (int(out_blocked) << 1))
-        blocked = out_blocked
-    res = []
-    for i, (net, _, _, cout, mean, n_s) in enumerate(plan):
-        a = ops.conv2d(buf[i * B:(i + 1) * B], pcs_out[i], bias=cout.bias, in_blocked=blocked)
-        res.append((a[:, :n_s], a[:, n_s:], False) if mean is None else (a, mean, True))
-    return res
 
 
 class wavelet_flow_subnetwork2D(wavelet_flow_subnetwork):

@@ -569,7 +569,6 @@ def conv3x3_couple(u, pc_bias, x, out, clamp_kind, clamp, pre_scale, rev, logdet
 
 
 BLOCKED_MAPS = True          # (tuning / ablation) False: the maps between the split-bf16 sub-network layers stay NCHW
-BLOCKED_UNET = False         # the same for the map between the two convolutions of a UNetConvBlock: built and tested, no gain (unet.py)
 SPLIT_7X7 = True             # (tuning / ablation) False: 7x7 convolutions stay on the fp32 MFMA kernel in split / bf16 precision
 VIRTUAL_CAT = True           # (tuning / ablation) False: the input cat(half, condition) of a coupling sub-network is materialised
 COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_raw | t] and a separate affine launch applies them
@@ -646,36 +645,6 @@ def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False, layout=0):
         e1.record()
         rec.add(key, e0, e1)
     return out
-
-
-def subnet_layer_group(x, packed, b3, b1, nprob, layout=0):
-    """``nprob`` independent layers of the same shape in ONE persistent launch (cwfa_subnet_layer_split_group_f32):
-    x [nprob * spp, 64, H, W] (sample b belongs to problem b // spp), ``packed`` the nprob split images back to back (uint8),
-    ``b3`` / ``b1`` [nprob, 64].  Returns y with x's shape (memory order per ``layout``, see subnet_layer)."""
-    L = _lib.lib()
-    x, xbs = planes(x, "x")
-    Bt, Cc, H, W = x.shape
-    if Cc != 64 or Bt % nprob or nprob > L.cwfa_subnet_layer_split_max_problems():
-        raise ValueError(f"subnet_layer_group: {Bt} samples of {Cc} channels do not split into {nprob} problems")
-    if packed.numel() != nprob * L.cwfa_subnet_layer_split_packed_bytes() or b3.numel() != nprob * 64 or b1.numel() != nprob * 64:
-        raise ValueError("subnet_layer_group: packed images / biases do not match nprob")
-    out = torch.empty((Bt, 64, H, W), dtype=torch.float32, device=x.device)
-    rec = conv_event_sink
-    if rec is not None:
-        key = ("L", 64, 64, H, W, Bt, "layer+split", False)
-        if rec.want(key):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-    check(L.cwfa_subnet_layer_split_group_f32(_p(x), _p(packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), nprob, Bt // nprob, H, W,
-                                              xbs, 64 * H * W, int(layout), _stream()), "subnet_layer_split_group")
-    if rec is not None and rec.want(key):
-        e1.record()
-        rec.add(key, e0, e1)
-    return out
-
-
-GROUP_LAYERS = False         # True: the k-th residual layers of the five independent sub-networks of a CAT step in ONE grouped launch
-#                              (networks.grouped_affine_parts); built and tested, measured 46.3 vs 46.4 volumes/s: no gain, left off
 
 
 # ------------------------------------------------------------------------------------------------ backward of the sub-networks
@@ -905,17 +874,14 @@ def conv3d_1k1(x, w1, b1, alpha, w2, b2):
 
 
 # ------------------------------------------------------------------------------------------------ LRNN helpers
-def channel_stats(x, blocked=False, out=None):
-    """double[2*C]: per-channel (sum, sumsq) over (B,H,W).  ``blocked``: x is a channel-blocked map ([C/8][H][W][8]).  ``out``: a
-    ZEROED float64[2*C] buffer to add into (bn_finish clears it again) instead of a fresh one."""
+def channel_stats(x, out=None):
+    """double[2*C]: per-channel (sum, sumsq) over (B,H,W).  ``out``: a ZEROED float64[2*C] buffer to add into (bn_finish clears
+    it again) instead of a fresh one."""
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
     st = out if out is not None else torch.zeros(2 * Cc, dtype=torch.float64, device=x.device)
-    if blocked:
-        check(L.cwfa_channel_stats_blocked8_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats_blocked8")
-    else:
-        check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
+    check(L.cwfa_channel_stats_f32(_p(x), _p(st), B, Cc, H * W, xbs, _stream()), "channel_stats")
     return st
 
 
@@ -1058,6 +1024,16 @@ _pack_epoch = 0
 def pack_epoch():
     """Generation counter of the packing-relevant options; a cached PackedConv with another epoch must be rebuilt."""
     return _pack_epoch
+
+
+def invalidate_packs():
+    """Drop every cached kernel-layout image (filter banks, packed biases, composed chain tables): they are keyed on
+    ``tensor._version`` / ``data_ptr()``, which an in-place write through ``.data`` (``m.bias.data *= 0.1``,
+    ``nn.init.*_(m.weight.data)`` -- the reference's own initialisers, networks.py:19-62) does NOT change.  The initialisers and
+    reset helpers of cwfa_amd.networks call this; call it yourself after any other ``.data`` edit of a parameter that has
+    already been used in a forward pass."""
+    global _pack_epoch
+    _pack_epoch += 1
 
 
 WINOGRAD_2D_DEFAULT = 512     # library default of the "winograd_2d" option (output-channel threshold of the 2-D kernel)

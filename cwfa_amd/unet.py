@@ -61,17 +61,19 @@ def _bn_batch_stats(bn):
 
 def _bn_stats_buffer(bn, device):
     """The layer's own float64 [2C] statistics buffer, zeroed (bn_finish clears it again after use; an exception in between
-    leaves the dirty flag set and the buffer is rebuilt).  Accumulated on the CURRENT stream only: two forwards of the same
-    module on different streams must not overlap."""
-    st = getattr(bn, "_cwfa_stats", None)
-    if st is None or st.device != device or getattr(bn, "_cwfa_stats_dirty", False):
-        st = bn._cwfa_stats = torch.zeros(2 * bn.num_features, dtype=torch.float64, device=device)
+    leaves the dirty flag set and the buffer is rebuilt).  One buffer per (device, stream): forwards of the same module on
+    different streams accumulate into different buffers."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    bufs = bn.__dict__.setdefault("_cwfa_stats", {})
+    st = bufs.get(key)
+    if st is None or getattr(bn, "_cwfa_stats_dirty", False):
+        st = bufs[key] = torch.zeros(2 * bn.num_features, dtype=torch.float64, device=device)
     bn._cwfa_stats_dirty = True
     return st
 
 
-def _bn_affine(bn, y, drop=None, blocked=False, stats=None):
-    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output; ``blocked``: channel-blocked map), times the
+def _bn_affine(bn, y, drop=None, stats=None):
+    """(scale, shift) of BatchNorm2d ``bn`` for its input ``y`` (raw conv+PReLU output), times the
     pending dropout factor ``drop`` (a _Drop or a ready [B,C] mask).  Train mode: the statistics come from the producing
     convolution's epilogue (``stats``: the buffer it added into, ops.conv2d(out_stats=)) or from one pass over ``y`` into the
     layer's own (kept zeroed) float64 buffer; then ONE launch for fold + running-buffer bookkeeping + dropout factor + re-zeroing."""
@@ -81,7 +83,7 @@ def _bn_affine(bn, y, drop=None, blocked=False, stats=None):
         st = stats
         if st is None:
             st = _bn_stats_buffer(bn, y.device)
-            ops.channel_stats(y, blocked=blocked, out=st)
+            ops.channel_stats(y, out=st)
         n = y.numel() // C
         track = bn.track_running_stats and bn.momentum is not None       # buffer bookkeeping, as nn.BatchNorm2d does
         out = ops.bn_finish(C, bn.weight, bn.bias, bn.eps, stats=st, count=float(n), running_mean=bn.running_mean if track else None,
@@ -156,15 +158,10 @@ class UNetConvBlock(nn.Module):
         aff = in_affine
         layers = self._layers()
         packs = [self._packed.get(conv) for conv, _, _ in layers]
-        blocked = False               # layout of x: the map BETWEEN the two convolutions is private to this block and CAN be kept
-        #                               channel-blocked ([C/8][H][W][8]) on the split-bf16 3x3 kernel (ops.BLOCKED_UNET; off:
-        #                               measured -4 % .. +1 % per convolution and a slower statistics pass, no gain per volume)
         for li, (conv, act, bn) in enumerate(layers):
             kind, alpha = self._act(act)
             sc, sh = aff if aff is not None else (None, None)
             add = in_add if li == 0 else None
-            out_blocked = (ops.BLOCKED_UNET and li == 0 and len(layers) == 2 and kind in (None, "prelu") and
-                           all(pc.split and pc.ks == 3 for pc in packs) and packs[0].cout % 8 == 0)
             if (_MATERIALIZE and ops._split_bf16 < 2 and (sc is not None or add is not None)
                     and (x.shape[2] * x.shape[3]) % 4 == 0):         # (the split / bf16 kernels apply the prologue for free)
                 # one streaming pass writes the BatchNorm (x mask, + skip) output, and the convolution runs without its
@@ -176,15 +173,14 @@ class UNetConvBlock(nn.Module):
             # kernel can do that (split-bf16 3x3, NCHW output)
             st = None
             if (STATS_IN_EPILOGUE and bn is not None and _bn_batch_stats(bn)
-                    and ops.conv_writes_stats(packs[li], kind, None, None, out_blocked)):
+                    and ops.conv_writes_stats(packs[li], kind)):
                 st = _bn_stats_buffer(bn, x.device)
             x = ops.conv2d(x, packs[li], bias=conv.bias, act=kind, prelu_alpha=alpha, in_scale=sc,
-                           in_shift=sh, in_add=add, in_blocked=blocked, out_blocked=out_blocked, out_stats=st)
-            blocked = out_blocked
+                           in_shift=sh, in_add=add, out_stats=st)
             last = li == len(layers) - 1
             m = out_mask if last else None
             if bn is not None:
-                aff = _bn_affine(bn, x, m, blocked=blocked, stats=st)
+                aff = _bn_affine(bn, x, m, stats=st)
             elif m is not None:
                 aff = _drop_affine(x.shape[1], m)
             else:

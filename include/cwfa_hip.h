@@ -206,8 +206,7 @@ typedef struct {
     int out_blocked8;         /* y is written channel-blocked [B][Cout/8][H][W][8]: cwfa_conv2d_f32 for 1x1 banks
                                  with 33..64 outputs, bias only (the first convolution of a coupling sub-network
                                  feeding cwfa_subnet_layer_split_f32 with layout bit 0); cwfa_conv3x3_split_f32
-                                 with a bias / PReLU epilogue (the first convolution of a UNetConvBlock; its
-                                 statistics: cwfa_channel_stats_blocked8_f32, its consumer: in_blocked8)       */
+                                 with a bias / PReLU epilogue (consumer: in_blocked8)                         */
     const float* in_cat;      /* cwfa_conv2d_f32, 1x1 banks with <= 64 outputs, no other in_*: the input is the channel
                                  concatenation cat(x, in_cat) WITHOUT materialising it (the input of a coupling
                                  sub-network, cat(half, *conditions): coupling_layers.py:74-87, all_in_one_block.py:
@@ -258,8 +257,6 @@ int cwfa_conv3d_1k1_split_f32(const float* x, const float* w1, const float* b1, 
 
 /* per-channel batch statistics for train-mode BatchNorm2d: stats[2*C] += (sum, sumsq) over (B,H,W), double */
 int cwfa_channel_stats_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream);
-/* the same for a channel-blocked map [B][C/8][HW][8] (cwfa_conv_opts.out_blocked8), C % 8 == 0, 16-byte aligned */
-int cwfa_channel_stats_blocked8_f32(const float* x, double* stats, int B, int C, int64_t HW, int64_t x_bs, void* stream);
 /* turn (sum,sumsq,count) or running (mean,var) into scale/shift: scale = w*rsqrt(var+eps), shift = b - mean*scale
  * stats != NULL: batch statistics (biased variance);  else running_mean / running_var.
  * mask_bc (nullable, [B*C]): per-(sample,channel) multiplier (F.dropout2d keep-mask / (1-p)); scale and shift are then
@@ -361,14 +358,6 @@ int64_t cwfa_subnet_layer_split_packed_bytes(void);
 int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream);
 int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H,
                                 int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
-/* Grouped form: `nprob` (<= cwfa_subnet_layer_split_max_problems()) independent layers of the same shape in ONE persistent launch --
- * x / y [nprob * samples_per_problem, 64, H, W], sample b belongs to problem b / samples_per_problem, `packed` holds the nprob
- * images back to back, b3 / b1 are [nprob][64].  The five sub-networks of a CAT step are independent of each other
- * (coupling_layers.py:475-500: their inputs are the conditions), so their k-th layers run as one launch: at batch 1 a launch
- * is only two tiles per CU, and its un-overlapped first fill and last epilogue cost ~10 %. */
-int cwfa_subnet_layer_split_max_problems(void);
-int cwfa_subnet_layer_split_group_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int nprob,
-                                      int samples_per_problem, int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
 /* layout: bit 0 = x, bit 1 = y is CHANNEL-BLOCKED, [B][8 blocks][H][W][8 channels] (same size and batch strides as NCHW, 16-byte
  * aligned), instead of NCHW planes.  The maps between the layers of one sub-network are private to it; blocked, a staging entry
  * of the kernel (8 channels of a pixel) is two 16-byte loads instead of eight 4-byte ones and the four channels a lane holds for

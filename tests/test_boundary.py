@@ -97,8 +97,6 @@ def test_layout_and_two_source_options_are_validated(built_lib):
     o.in_blocked8 = 1                                                        # blocked input is read by the split 3x3 kernel only
     assert L.cwfa_conv2d_f32(p, p, p, 1, 64, 8, 8, 64, 1, 4096, 4096, ctypes.byref(o), None) == -1
     assert L.cwfa_subnet_layer_split_f32(p, p, p, p, p, 1, 8, 8, 4096, 4096, 7, None) == -1        # layout not in 0..3
-    assert L.cwfa_subnet_layer_split_group_f32(p, p, p, p, p, 6, 1, 8, 8, 4096, 4096, 0, None) == -2  # more than 5 problems
-    assert L.cwfa_subnet_layer_split_max_problems() == 5
     assert L.cwfa_conv7x7_split_packed_bytes(65, 64) == -1 and L.cwfa_conv7x7_split_packed_bytes(64, 64) == 98 * 3 * 4 * 64 * 16
     assert L.cwfa_haar3d_fwd_f32(p, p, 1, 3, 8, 8, 1, 0.5, 192, None) == -2                         # odd depth
 

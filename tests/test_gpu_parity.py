@@ -1468,68 +1468,6 @@ def test_split_layer_channel_blocked_layouts(shape):
         ops.set_precision("fp32")
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_grouped_subnet_layers_equal_the_separate_launches(B):
-    """The five sub-networks of a CAT step with their k-th residual layers in ONE persistent launch each
-    (cwfa_subnet_layer_split_group_f32: per-problem filter banks and biases) against one launch per sub-network and layer --
-    the same kernel arithmetic, bit-identical -- forward and inverse, ragged tiles, batch > 1."""
-    from cwfa_amd import CWFA, ops
-    torch.manual_seed(1)
-    np.random.seed(1)
-    conv_inn, cond_nets = CWFA.build_networks(16, 40, 2, with_lrnn=False, cond_chans=4, device="cuda")    # 64 internal channels
-    gi = conv_inn[0]
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(B, 16, 40, 40, generator=g).cuda()
-    c = [torch.randn(B, 8, 40, 40, generator=g).cuda(), 0.1 * torch.randn(B, 8, 40, 40, generator=g).cuda()]
-    low = torch.randn(B, 8, 40, 40, generator=g).cuda()
-    calls = []
-    real = ops.subnet_layer_group
-    ops.set_precision("split_bf16")
-    try:
-        outs = []
-        for flag in (True, False):
-            ops.GROUP_LAYERS = flag
-            ops.subnet_layer_group = lambda *a, **k: (calls.append(flag), real(*a, **k))[1]
-            with torch.no_grad():
-                (z, lo), j = gi(x, c=c)
-                xi, ji = gi([None, low], c=c, rev=True)
-            outs.append((z, lo, j, xi, ji))
-        assert calls == [True] * 6, calls                      # three grouped launches per direction, none when switched off
-        for a, b in zip(*outs):
-            assert torch.equal(a, b)
-    finally:
-        ops.subnet_layer_group = real
-        ops.GROUP_LAYERS = False
-        ops.set_precision("fp32")
-
-
-def test_unet_block_channel_blocked_intermediate():
-    """UNetConvBlock in split precision: the map between its two convolutions channel-blocked (16-byte stores in the first
-    convolution, BatchNorm statistics by cwfa_channel_stats_blocked8_f32, 16-byte staging loads + BatchNorm-on-load in the
-    second) against the NCHW form of the same kernels, and the blocked statistics kernel against the plain one."""
-    from cwfa_amd import ops, unet
-    torch.manual_seed(2)
-    blk = unet.UNetConvBlock(24, 64, True, True, activation=torch.nn.PReLU).cuda().train()
-    x = torch.randn(2, 24, 37, 50, device="cuda")
-    ops.set_precision("split_bf16")
-    try:
-        outs = []
-        for flag in (True, False):
-            ops.BLOCKED_UNET = flag
-            torch.manual_seed(0)
-            for m in blk.block:
-                if isinstance(m, torch.nn.BatchNorm2d):
-                    m.reset_running_stats()
-            with torch.no_grad():
-                outs.append(blk(x))
-        assert_close(outs[0], outs[1], 1e-6, "blocked vs NCHW intermediate")
-        y = torch.randn(2, 64, 37, 50, device="cuda")
-        assert_close(ops.channel_stats(_to_blocked(y), blocked=True), ops.channel_stats(y), 1e-12, "blocked statistics")
-    finally:
-        ops.BLOCKED_UNET = False
-        ops.set_precision("fp32")
-
-
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
@@ -1640,3 +1578,224 @@ def test_bench_line_contract_at_a_small_size(extra):
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and rf["achieved"] / rf["peak"] == pytest.approx(rf["frac"])
     assert d["roofline_dwt"]["bound"] == "hbm" and 0 < d["roofline_dwt"]["frac"] <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------ API surface not on the plan path
+def test_sequence_inn_forward_and_inverse():
+    """SequenceINN.forward (sequence_inn.py:65-101): a conditioned chain ActNorm -> PermuteRandom -> GLOW -> PermuteDim against
+    the same modules applied one by one with the oracle's arithmetic -- outputs, summed log-det, the inverse and the tuple form."""
+    from cwfa_amd import networks as N, INN_utils
+    from cwfa_amd.FrEIA import framework as Ff, modules as Fm
+    from oracle import cwfa_oracle as O
+    N.networks_n_chans = 8
+    torch.manual_seed(5)
+    np.random.seed(5)
+    C_, H, W, B = 6, 8, 16, 2
+    seq = Ff.SequenceINN(C_, H, W)
+    seq.append(Fm.ActNorm)
+    seq.append(Fm.PermuteRandom, seed=3)
+    seq.append(Fm.GLOWCouplingBlock, cond=0, cond_shape=(4, H, W), subnet_constructor=N.wavelet_flow_subnetwork2D, clamp=1.5,
+               clamp_activation="ATAN")
+    seq.append(INN_utils.PermuteDim, seed=4)
+    seq = seq.cuda().eval()
+    assert [tuple(s) for s in seq.shapes] == [(C_, H, W)] * 5
+    gen = torch.Generator().manual_seed(6)
+    x = (1.5 * torch.randn(B, C_, H, W, generator=gen) - 0.3)
+    c = torch.randn(B, 4, H, W, generator=gen)
+    with torch.no_grad():
+        z, j = seq(x.cuda(), c=[c.cuda()])
+        xr, jr = seq(z, c=[c.cuda()], rev=True)
+    an, pr, glow, pd = list(seq.module_list)
+    assert an.init_on_next_batch is False
+    sc, bi = O.actnorm_init(x)
+    v, j0 = O.actnorm(sc, bi, x, False)
+    v = O.gather_axis(v, pr.perm.cpu(), 1)
+    sd = {"b." + k: t.detach().cpu() for k, t in glow.state_dict().items()}
+    v, j1 = O.block_two_sided(sd, "b.", v, [c], False, "GLOW", clamp=1.5, kind="ATAN")
+    v = O.gather_axis(v, pd.perm.cpu(), pd.axis)
+    assert_close(z, v, 1e-5, "SequenceINN forward")
+    assert_close(j, j0 + j1, 1e-5, "SequenceINN log-det")
+    assert_close(xr, x, 1e-5, "SequenceINN inverse")
+    assert_close(jr, -(j0 + j1), 1e-5)
+    seq.force_tuple_output = True
+    with torch.no_grad():
+        zt, _ = seq((x.cuda(),), c=[c.cuda()])
+    assert isinstance(zt, (tuple, list)) and torch.equal(zt[0], z)
+
+
+def test_reset_actnorm_rearms_the_data_dependent_init():
+    """reset_ActNorm (networks.py:137-151): the first n ActNorm layers are re-armed; the next pass -- here the DEFAULT inverse
+    pass with an all-zero latent given as None, the direction the reference's ActNorm initialises from just as well
+    (invertible_resnet.py:68-72) -- re-initialises them from its batch, after which the fused plan runs again."""
+    from cwfa_amd import networks as N, INN_utils
+    from cwfa_amd.FrEIA import framework as Ff, modules as Fm
+    from oracle import cwfa_oracle as O
+    N.networks_n_chans = 8
+    torch.manual_seed(7)
+    np.random.seed(7)
+    D, H, W, B = 8, 8, 64, 2
+    C_ = D // 2
+    nodes = [Ff.InputNode(D, H, W, name="input")]
+    nodes.append(Ff.Node(nodes[-1], INN_utils.HaarTransform1D, {"order_by_wavelet": True}, name="haar"))
+    split = Ff.Node(nodes[-1], Fm.Split, {"section_sizes": (C_, C_), "dim": 0}, name="split")
+    nodes.append(split)
+    cond = Ff.ConditionNode(C_, H, W, name="cond")
+    nodes.append(cond)
+    nodes.append(Ff.Node(split.out1, Fm.ConditionalAffineTransform, {"subnet_constructor": N.wavelet_flow_subnetwork2D},
+                         conditions=[cond], name="cat0"))
+    nodes.append(Ff.Node(nodes[-1], Fm.ActNorm, {}, name="an0"))
+    nodes.append(Ff.Node(nodes[-1], Fm.ActNorm, {}, name="an1"))
+    nodes.append(Ff.OutputNode(nodes[-1], name="z"))
+    nodes.append(Ff.OutputNode(split.out0, name="low"))
+    g = Ff.GraphINN(nodes).cuda()
+    gen = torch.Generator().manual_seed(8)
+    x = (2.0 * torch.randn(B, D, H, W, generator=gen) + 0.5).cuda()
+    c = [torch.randn(B, C_, H, W, generator=gen).cuda()]
+    low = torch.randn(B, C_, H, W, generator=gen).cuda()
+    an = [m for m in g.module_list if isinstance(m, Fm.ActNorm)]
+    # a fresh graph: the default inverse pass (z = None, an all-zero latent) must RUN although both ActNorms are still waiting for
+    # their batch (round 2 raised ValueError here).  Like the reference's, an ActNorm that initialises itself on an all-zero batch
+    # gets scale = log(1 / 0) = inf -- the reference's own behaviour (invertible_resnet.py:59-60), nothing to "fix"
+    assert g._plan is not None and g._plan.needs_walk()
+    with torch.no_grad():
+        x0, _ = g([None, low], c=c, rev=True)
+    assert not g._plan.needs_walk() and all(not m.init_on_next_batch for m in an)
+    assert x0.shape == x.shape and torch.isinf(an[1].scale).all()
+    # initialisation from the inverse direction on a real latent: the LAST ActNorm sees z first (invertible_resnet.py:68-72)
+    N.reset_ActNorm(g)
+    zin = (1.7 * torch.randn(B, C_, H, W, generator=gen) + 0.2).cuda()
+    with torch.no_grad():
+        x1, _ = g([zin, low], c=c, rev=True)
+    sc, bi = O.actnorm_init(zin.cpu())
+    assert_close(an[1].scale, sc, 1e-5, "ActNorm initialised from the inverse direction")
+    assert_close(an[1].bias, bi, 1e-5)
+    assert torch.isfinite(x1).all()
+    with torch.no_grad():
+        N.reset_ActNorm(g)
+        g(x, c=c)
+    s_old = [m.scale.detach().clone() for m in an]
+    _, n = N.reset_ActNorm(g, n_to_reset=1)
+    assert n == 1 and an[0].init_on_next_batch and not an[1].init_on_next_batch and g._plan.needs_walk()
+    _, n = N.reset_ActNorm(g)
+    assert n == 2 and all(m.init_on_next_batch for m in an)
+    with torch.no_grad():
+        (z, lo), j = g(3.0 * x, c=c)                                    # re-initialised on this batch: node walk
+    assert not g._plan.needs_walk()
+    assert not torch.equal(an[0].scale, s_old[0])
+    # after the init the output of an ActNorm has zero mean and unit (unbiased) std per channel; the last one feeds z
+    flat = z.transpose(0, 1).reshape(C_, -1)
+    assert float(flat.mean(1).abs().max()) < 1e-4 and float((flat.std(1) - 1).abs().max()) < 1e-4
+    with torch.no_grad():
+        (z2, _), j2 = g(3.0 * x, c=c)                                   # the fused plan on the new parameters
+    assert_close(z2, z, 1e-5, "plan after reset vs the initialising walk")
+    assert_close(j2, j, 1e-5)
+
+
+def test_log_jacobian_numerical_matches_the_analytic_logdet():
+    """GraphINN.log_jacobian_numerical (graph_inn.py:369-407) on a tiny conditioned graph: central differences of the HIP
+    forward against the log-det the blocks report, forward and inverse."""
+    from cwfa_amd import networks as N
+    from cwfa_amd.FrEIA import framework as Ff, modules as Fm
+    N.networks_n_chans = 4
+    torch.manual_seed(9)
+    np.random.seed(9)
+    C_, H, W, B = 2, 2, 2, 2
+    inp = Ff.InputNode(C_, H, W, name="in")
+    cond = Ff.ConditionNode(1, H, W, name="c")
+    b1 = Ff.Node(inp, Fm.GLOWCouplingBlock, {"subnet_constructor": N.wavelet_flow_subnetwork2D, "clamp": 1.0}, conditions=[cond], name="g1")
+    p1 = Ff.Node(b1, Fm.PermuteRandom, {"seed": 1}, name="p1")
+    b2 = Ff.Node(p1, Fm.ConditionalAffineTransform, {"subnet_constructor": N.wavelet_flow_subnetwork2D}, conditions=[cond], name="c2")
+    g = Ff.GraphINN([inp, cond, b1, p1, b2, Ff.OutputNode(b2, name="out")]).cuda().eval()
+    for m in g.modules():                                 # default-init sub-networks give s ~ 1e-2: scale them up to a visible log-det
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data *= 2.0
+    from cwfa_amd import ops
+    ops.invalidate_packs()
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(B, C_, H, W, generator=gen).cuda()
+    c = [torch.randn(B, 1, H, W, generator=gen).cuda()]
+    with torch.no_grad():
+        z, j = g(x, c=c)
+        jn = g.log_jacobian_numerical(x, c=c, h=4e-3)
+        _, jr = g(z, c=c, rev=True)
+        jrn = g.log_jacobian_numerical(z, c=c, rev=True, h=1e-3)
+    assert float(j.abs().min()) > 1e-3, "the test needs a non-trivial log-det"
+    # central differences in fp32: truncation ~h^2, round-off ~1e-7 / h per Jacobian entry
+    assert torch.allclose(jn, j, atol=1e-2, rtol=5e-3), (jn, j)
+    assert torch.allclose(jrn, jr, atol=5e-2, rtol=1e-2), (jrn, jr)      # (the inverse map is the more curved one: smaller h, more round-off)
+    assert torch.allclose(jr, -j, atol=1e-5)
+
+
+@pytest.mark.parametrize("temperature", [0.7, 2.0])
+def test_truncated_normal_sampler_moments(temperature):
+    """sample_z_truncated with T != 0 (CWFA.py:47-64 via utils.py:42-82: N(0,1) truncated to [-T, T]) -- a path that raises
+    NameError in the reference itself, so there is nothing to match but the distribution: support, mean, variance and the
+    central-interval mass of 4 M draws against the closed forms."""
+    import math
+    from cwfa_amd import CWFA
+    torch.manual_seed(11)
+    z = CWFA.sample_z_truncated((4, 4, 512, 512), device="cuda", temperature=temperature)
+    assert z.shape == (4, 4, 512, 512) and z.is_cuda
+    assert float(z.abs().max()) <= temperature
+    T_ = temperature
+    phi = math.exp(-T_ * T_ / 2) / math.sqrt(2 * math.pi)
+    mass = math.erf(T_ / math.sqrt(2))
+    var = 1 - 2 * T_ * phi / mass                         # variance of the symmetric truncation
+    n = z.numel()
+    assert abs(float(z.mean())) < 5 * math.sqrt(var / n)
+    assert abs(float(z.var()) - var) < 0.01 * var
+    inner = math.erf(0.5 * T_ / math.sqrt(2)) / mass      # P(|z| < T/2)
+    assert abs(float((z.abs() < 0.5 * T_).float().mean()) - inner) < 5 * math.sqrt(inner * (1 - inner) / n)
+    assert torch.equal(CWFA.sample_z_truncated((2, 3), device="cuda", temperature=0), torch.zeros(2, 3, device="cuda"))
+
+
+def test_tanh_clamp_small_arguments_keep_their_logdet():
+    """the TANH soft clamp of AllInOneBlock-style stages near s_raw = 0 (freshly initialised sub-networks):
+    values and the summed log-det of ops.affine against float64, relative to the log-det's own size (the hardware-exp form
+    1 - 2 / (e^{2x} + 1) alone cancels there: ~1e-3 relative at |x| = 1e-4)."""
+    from cwfa_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    B, C_, H, W = 2, 6, 16, 32
+    x = torch.randn(B, C_, H, W, generator=gen)
+    t = torch.randn(B, C_, H, W, generator=gen)
+    for mag in (1e-4, 1e-3, 1e-2, 0.2, 0.5, 3.0):
+        s_raw = mag * (torch.rand(B, C_, H, W, generator=gen) + 0.5)          # one sign: the sum does not cancel
+        s64 = 2.0 * torch.tanh(0.1 * s_raw.double())
+        ref = x.double() * s64.exp() + 0.1 * t.double()                 # (AllInOneBlock scales s AND t: all_in_one_block.py:215)
+        ld = torch.zeros(B, dtype=torch.float64, device="cuda")
+        y = ops.affine(x.cuda(), ops.stage(s_raw.cuda(), t.cuda(), "TANH", 2.0, 0.1), False, logdet=ld)
+        assert_close(y, ref, 1e-6, f"TANH stage at |s_raw| ~ {mag}")
+        want = s64.sum((1, 2, 3))
+        assert float(((ld.cpu() - want) / want).abs().max()) < 2e-6, (mag, ld.cpu(), want)
+
+
+def test_in_place_parameter_edits_need_invalidate_packs():
+    """packed filter banks / bias rows are keyed on (_version, data_ptr), which `.data` edits do not change.
+    The initialisers of cwfa_amd.networks (which edit through `.data`, like the reference's: networks.py:19-62) call
+    ops.invalidate_packs(); after them a GLOW block on the coupling-epilogue path must see the new weights AND biases."""
+    from cwfa_amd import networks as N, ops
+    from cwfa_amd.FrEIA import modules as Fm
+    N.networks_n_chans = 64
+    torch.manual_seed(13)
+    blk = Fm.GLOWCouplingBlock([(8, 16, 32)], dims_c=[(4, 16, 32)], subnet_constructor=N.wavelet_flow_subnetwork2D).cuda().eval()
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(1, 8, 16, 32, generator=gen).cuda()
+    c = [torch.randn(1, 4, 16, 32, generator=gen).cuda()]
+    ops.set_precision("split_bf16")
+    try:
+        with torch.no_grad():
+            (y0,), _ = blk((x,), c=c)
+            torch.manual_seed(15)
+            blk.apply(N.subnet_initialization)                      # `.data` edits + invalidate_packs
+            for m in blk.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+                    m.bias.data += 0.5
+            ops.invalidate_packs()
+            (y1,), _ = blk((x,), c=c)
+        ops.set_precision("fp32")
+        with torch.no_grad():
+            (y2,), _ = blk((x,), c=c)                               # the fp32 path reads the parameters live
+    finally:
+        ops.set_precision("fp32")
+    assert not torch.equal(y0, y1)
+    assert_close(y1, y2, 1e-5, "re-packed split path vs live fp32 path")
