@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from ... import autograd as AG
 from ... import ops
 from ..modules.base import InvertibleModule
 
@@ -204,7 +205,20 @@ class GraphINN(InvertibleModule):
         c = [] if c is None else list(c)
         if len(c) != len(self.condition_nodes):
             raise ValueError(f"Got {len(c)} conditions, but expected {len(self.condition_nodes)}.")
-        if self._plan is not None and not intermediate_outputs and not self._plan.needs_walk():
+        if AG.tracking(list(x_or_z), c, self):
+            # torch would record a graph (training): the all-CAT step keeps its fused chain as ONE autograd node per direction;
+            # every other graph goes node by node, each module an autograd node of its own (cwfa_amd.autograd)
+            plan = self._plan
+            if (type(plan) is _CatStepPlan and not intermediate_outputs and not any(k == "act" for k, _ in plan.chain)
+                    and all(hasattr(n.module.subnet, "affine_parts") for k, n in plan.chain if k == "cat")):
+                res = plan.run_tracked(x_or_z, c, rev)
+                if not jac:
+                    res = (res[0], None)                # as the inference plan: no log-det asked for, none returned
+                if sumsq is not None and not rev:      # the ||Z||^2 extension: one extra pass here (the inference plan fuses it)
+                    zt = res[0][plan.flow_out_idx].detach()
+                    sumsq += ops.sample_stats(zt.reshape(1, -1, 1, 1))[1]
+                return res
+        elif self._plan is not None and not intermediate_outputs and not self._plan.needs_walk():
             return self._plan.run(x_or_z, c, rev, sumsq, jac)
         if any(t is None for t in x_or_z):
             # None = an all-zero latent (the default T = 0 inverse pass, CWFA.py:54-55).  The fused plans never read it; the node
@@ -214,7 +228,12 @@ class GraphINN(InvertibleModule):
                 raise ValueError("None (an all-zero latent) is only understood for rev=True with at least one tensor input")
             x_or_z = tuple(t if t is not None else torch.zeros((ref.shape[0],) + tuple(shp), dtype=ref.dtype, device=ref.device)
                            for t, shp in zip(x_or_z, self.global_out_shapes))
-        return self._walk(x_or_z, c, rev, jac, intermediate_outputs)
+        res = self._walk(x_or_z, c, rev, jac, intermediate_outputs)
+        if sumsq is not None and not rev and not intermediate_outputs:       # the ||Z||^2 extension outside the fused plans: one extra pass
+            outs = res[0]
+            zt = (outs[0] if isinstance(outs, (tuple, list)) else outs).detach()
+            sumsq += ops.sample_stats(zt.contiguous().reshape(1, -1, 1, 1))[1]
+        return res
 
     def _walk(self, x_or_z, c, rev, jac, intermediate_outputs):
         """Node-by-node execution (any graph).  Same data flow as graph_inn.py:259-326."""
@@ -371,6 +390,51 @@ class _CatStepPlan:
             table = next((t for t in keep if t.dtype == torch.int64), None) if st.perm else None
             out.append((table, int(st.perm_axis)))
         return out
+
+    def run_tracked(self, x_or_z, c, rev):
+        """``run`` with torch recording a graph: the sub-networks are autograd nodes (cwfa_amd.autograd.subnet), the chain launch
+        is one node whose backward (ops.chain_bwd / chain_inv_bwd) recomputes every stage input by inverting the stage."""
+        g = self.graph
+        cond_of = dict(zip(g.condition_nodes, c))
+        cache = {}
+
+        def coefficients(module, parts):
+            hit = cache.get(id(module))
+            if hit is None:
+                hit = cache[id(module)] = module.coefficients(parts)
+            return hit
+
+        def coef_of(stages):            # per coefficient stage, in stage order, the tensors its struct was built from
+            out = []
+            for kind, obj in (list(reversed(self.chain)) if stages is rstages else self.chain):
+                if kind == "cat":
+                    s_raw, t, _ = cache[id(obj.module)]
+                    out.append((s_raw, t))
+            return out
+
+        first = next(t for t in x_or_z if t is not None)
+        fstages, pending = self._stages(cond_of, False, coefficients=coefficients)
+        final_perm = None
+        if pending is not None:
+            if pending[1] == 1:
+                final_perm = pending[0]
+            else:
+                fstages.append(ops.stage(None, None, perm=pending[0], axis=pending[1]))
+        rstages = None
+        if not rev:
+            shp = (first.shape[1] // 2, first.shape[2], first.shape[3])
+            tabs = self._composed(False, self._perms_of(fstages), final_perm, shp, first.device)
+            z, low, ld = AG.chain_fwd(first, fstages, final_perm, tabs, coef_of(fstages))
+            outs = [None, None]
+            outs[self.flow_out_idx], outs[self.low_out_idx] = z, low
+            return tuple(outs), ld
+        rstages, rpending = self._stages(cond_of, True, coefficients=coefficients)
+        if rpending is not None:
+            rstages.append(ops.stage(None, None, perm=rpending[0], axis=rpending[1]))
+        z, low = x_or_z[self.flow_out_idx], x_or_z[self.low_out_idx]
+        rtabs = self._composed(True, self._perms_of(rstages), None, tuple(low.shape[1:]), low.device)
+        xhat, ld = AG.chain_inv(z, low, rstages, rtabs, fstages, final_perm, coef_of(fstages))
+        return (xhat if not g.force_tuple_output else (xhat,)), ld
 
     def run(self, x_or_z, c, rev, sumsq=None, jac=True):
         """``jac=False`` skips the log-det reduction (the reconstruction loop discards it, CWFA.py:912) and returns

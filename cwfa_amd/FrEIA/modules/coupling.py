@@ -14,6 +14,7 @@ from typing import Callable, Union
 import torch
 import torch.nn as nn
 
+from ... import autograd as AG
 from ... import ops
 from .base import InvertibleModule, as_jac, new_logdet
 
@@ -25,7 +26,7 @@ def subnet_st(net, parts, n_s):
     """Run a sub-network on the (virtual) channel concatenation of ``parts`` -> (s_raw, t, t_neg_div_sqrt2)."""
     if hasattr(net, "affine_parts"):
         return net.affine_parts(list(parts), n_s)
-    u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+    u = parts[0] if len(parts) == 1 else (AG.concat(parts) if AG.tracking(list(parts)) else ops.concat_channels(parts))
     a = net(u)
     return a[:, :n_s], a[:, n_s:], False
 
@@ -78,8 +79,30 @@ class _TwoSided(_BaseCouplingBlock):
     def _has_jac(self):
         return not self._gin
 
+    def _forward_tracked(self, x0, c, rev):
+        """The same data flow as ``forward`` with every piece an autograd node (cwfa_amd.autograd): sub-networks, affine stages,
+        the channel concatenation of the two halves.  No in-place writes, nothing fused across the coupling."""
+        l1 = self.split_len1
+        x1, x2 = x0[:, :l1], x0[:, l1:]
+
+        def couple(xa, parts, which, n_out):
+            s_raw, t = self._nets(which, parts, n_out)
+            if self.clamp_kind is None:
+                raise NotImplementedError("custom clamp_activation callables have no HIP implementation")
+            return AG.affine(xa, s_raw, t, rev, self.clamp_kind, self.clamp, gin=self._gin)
+
+        if not rev:
+            y1, j1 = couple(x1, self._cond(x2, c), 2, l1)
+            y2, j2 = couple(x2, self._cond(y1, c), 1, self.split_len2)
+        else:
+            y2, j2 = couple(x2, self._cond(x1, c), 1, self.split_len2)
+            y1, j1 = couple(x1, self._cond(y2, c), 2, l1)
+        return (AG.concat([y1, y2]),), ((j1 + j2) if self._has_jac() else 0.)
+
     def forward(self, x, c=[], rev=False, jac=True):
         x0 = x[0]
+        if AG.tracking(x0, list(c), self):
+            return self._forward_tracked(x0, c, rev)
         l1 = self.split_len1
         x1, x2 = x0[:, :l1], x0[:, l1:]
         out = torch.empty_like(x0, memory_format=torch.contiguous_format)
@@ -118,7 +141,7 @@ class NICECouplingBlock(_TwoSided):
 
     def _nets(self, which, parts, n_out):
         net = self.F if which == 2 else self.G
-        u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+        u = parts[0] if len(parts) == 1 else (AG.concat(parts) if AG.tracking(list(parts)) else ops.concat_channels(parts))
         return None, net(u)
 
 
@@ -134,7 +157,7 @@ class RNVPCouplingBlock(_TwoSided):
         self.subnet_t2 = subnet_constructor(self.split_len2 + self.condition_length, self.split_len1)
 
     def _nets(self, which, parts, n_out):
-        u = parts[0] if len(parts) == 1 else ops.concat_channels(parts)
+        u = parts[0] if len(parts) == 1 else (AG.concat(parts) if AG.tracking(list(parts)) else ops.concat_channels(parts))
         return getattr(self, f"subnet_s{which}")(u), getattr(self, f"subnet_t{which}")(u)
 
 
@@ -173,6 +196,12 @@ class AffineCouplingOneSided(_BaseCouplingBlock):
         x0 = x[0]
         l1 = self.split_len1
         x1, x2 = x0[:, :l1], x0[:, l1:]
+        if AG.tracking(x0, list(c), self):            # every piece an autograd node (cwfa_amd.autograd)
+            s_raw, t, _ = subnet_st(self.subnet, self._cond(x1, c), self.split_len2)
+            if self.clamp_kind is None:
+                raise NotImplementedError("custom clamp_activation callables have no HIP implementation")
+            y2, j = AG.affine(x2, s_raw, t, rev, self.clamp_kind, self.clamp)
+            return (AG.concat([x1, y2]),), j
         out = torch.empty(x0.shape, dtype=torch.float32, device=x0.device)
         ops.copy_channels(x1, out[:, :l1])            # x1 passes through; the x2 half is written by the coupling below
         acc = new_logdet(x0)
@@ -204,6 +233,12 @@ class ConditionalAffineTransform(_BaseCouplingBlock):
         return self._stage(s_raw, t, t_neg_div_sqrt2=tneg, perm=perm, axis=axis)
 
     def forward(self, x, c=[], rev=False, jac=True):
+        if AG.tracking(x[0], list(c), self):
+            s_raw, t, tneg = self.coefficients(c)
+            if self.clamp_kind is None:
+                raise NotImplementedError("custom clamp_activation callables have no HIP implementation")
+            y, j = AG.affine(x[0], s_raw, t, rev, self.clamp_kind, self.clamp, t_neg_div_sqrt2=tneg)
+            return (y,), j
         acc = new_logdet(x[0])
         y = ops.affine(x[0], self.stage(c), rev, logdet=acc)
         return (y,), as_jac(acc)
@@ -317,7 +352,60 @@ class AllInOneBlock(InvertibleModule):
             return ops.gather(x, mix[1] if inverse else mix[0], 1)
         return ops.conv2d(x, mix[1] if inverse else mix[0])
 
+    def _forward_tracked(self, x0, c, rev):
+        """all_in_one_block.py:206-268 with every piece an autograd node (cwfa_amd.autograd).  The [C]-sized global-affine
+        activation runs through torch's own graph; hard permutations are gathers; the coupling is one affine stage."""
+        wp = self._construct_householder_permutation() if self.householder else self.w_perm      # (the product carries its graph)
+        w = wp[:, :, 0, 0]
+        hard = (not self.householder and bool(((w == 0) | (w == 1)).all()) and bool((w.sum(0) == 1).all() and (w.sum(1) == 1).all()))
+        if hard:
+            p_fwd, p_inv = w.argmax(1).contiguous(), w.t().argmax(1).contiguous()     # fwd: out[:, i] = v[:, p_fwd[i]]
+            mix = lambda v, inverse: AG.gather(v, p_inv if inverse else p_fwd, 1, p_fwd if inverse else p_inv)   # noqa: E731
+        else:          # dense mix: y = conv1x1(x, w) / conv1x1(x, w^T) (:191-204)
+            mix = lambda v, inverse: AG.mix1x1(v, wp.transpose(0, 1) if inverse else wp)                          # noqa: E731
+        g = self.global_scale.reshape(-1)
+        if self.GIN:
+            scale = torch.ones_like(g)                                                 # :183-185
+        elif self.global_affine_type == 'SOFTPLUS':
+            scale = 0.1 * torch.nn.functional.softplus(g, beta=0.5)
+        elif self.global_affine_type == 'SIGMOID':
+            scale = 10 * torch.sigmoid(g - 2.)
+        else:
+            scale = torch.exp(g)
+        offset = self.global_offset.reshape(-1)
+        l1, l2 = self.splits
+        n_pix = x0.shape[2] * x0.shape[3]
+        if rev:                                                                    # :191-193: undo permutation, then global affine
+            v = AG.channel_affine(mix(x0, True), scale, offset, inverse=True)
+        elif self.reverse_pre_permute:
+            v = mix(x0, True)
+        else:
+            v = x0
+        x1, x2 = v[:, :l1], v[:, l1:]
+        parts = [x1, *c] if self.conditional else [x1]
+        s_raw, t, _ = subnet_st(self.subnet, parts, l2)
+        if self.GIN:
+            # s <- s - mean_{C,H,W}(s) per sample (:218-219), log-det 0: the plain coupling and a per-sample factor exp(-+mean)
+            m = AG.clamped_sum(s_raw, "TANH", self.clamp, 0.1) / float(l2 * n_pix)
+            if rev:
+                y2, _ = AG.affine(x2, s_raw, t, True, "TANH", self.clamp, pre_scale=0.1)
+                y2 = AG.scale_samples(y2, torch.exp(m))
+            else:
+                y2, _ = AG.affine(AG.scale_samples(x2, torch.exp(-m)), s_raw, t, False, "TANH", self.clamp, pre_scale=0.1)
+            j = torch.zeros(x0.shape[0], dtype=torch.float32, device=x0.device)
+        else:
+            y2, j = AG.affine(x2, s_raw, t, rev, "TANH", self.clamp, pre_scale=0.1)
+        u = AG.concat([x1, y2])
+        if rev:
+            out = mix(u, False) if self.reverse_pre_permute else u
+        else:
+            out = mix(AG.channel_affine(u, scale, offset, inverse=False), False)
+        j = j + (-1) ** int(rev) * n_pix * torch.log(scale).sum()
+        return (out,), j
+
     def forward(self, x, c=[], rev=False, jac=True):
+        if AG.tracking(x[0], list(c), self):
+            return self._forward_tracked(x[0], c, rev)
         hard, mix, scale, offset, log_scale_sum = self._prepare()
         x0 = x[0]
         l1, l2 = self.splits

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import autograd as AG
 from ... import ops
 from .base import InvertibleModule
 
@@ -45,6 +46,8 @@ class PermuteRandom(InvertibleModule):
         return self.perm_inv if rev else self.perm
 
     def forward(self, x, rev=False, jac=True):
+        if AG.tracking(x[0]):
+            return [AG.gather(x[0], self.table(rev), 1, self.table(not rev))], 0.
         return [ops.gather(x[0], self.table(rev), 1)], 0.
 
     def output_dims(self, input_dims):
@@ -116,7 +119,7 @@ class Split(InvertibleModule):
         if self.dim != 0:
             raise NotImplementedError("cwfa_amd Split: only the channel axis (dim=0) is on the HIP path")
         if rev:
-            return [ops.concat_channels(list(x))], 0
+            return [AG.concat(list(x)) if AG.tracking(list(x)) else ops.concat_channels(list(x))], 0
         return torch.split(x[0], self.split_size_or_sections, dim=1), 0     # views, no data movement
 
     def output_dims(self, input_dims):
@@ -148,7 +151,7 @@ class Concat(InvertibleModule):
             raise NotImplementedError("cwfa_amd Concat: only the channel axis (dim=0) is on the HIP path")
         if rev:
             return torch.split(x[0], self.split_size_or_sections, dim=1), 0
-        return [ops.concat_channels(list(x))], 0
+        return [AG.concat(list(x)) if AG.tracking(list(x)) else ops.concat_channels(list(x))], 0
 
     def output_dims(self, input_dims):
         assert len(input_dims) > 1, "Concatenation only makes sense for multiple inputs"
@@ -275,6 +278,9 @@ class ActNorm(InvertibleModule):
         if self.init_on_next_batch:
             self._initialize_with_data(x[0])
         j = (self.scale.sum() * np.prod(self.dims_in[1:])).repeat(x[0].shape[0])
+        if AG.tracking(x[0], self.scale, self.bias):         # scale / bias through torch's own graph ([C]-sized), the map through the HIP node
+            y = AG.channel_affine(x[0], self.scale.exp().reshape(-1), self.bias.reshape(-1), inverse=rev)
+            return [y], (-j if rev else j)
         es = self.scale.detach().exp().reshape(-1).contiguous()
         bs = self.bias.detach().reshape(-1).contiguous()
         if not rev:

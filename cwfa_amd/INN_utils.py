@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 from .FrEIA import modules as Fm
 
@@ -43,6 +44,8 @@ class PermuteDim(Fm.InvertibleModule):
         return self.perm_inv if rev else self.perm
 
     def forward(self, x, rev=False, jac=True):
+        if AG.tracking(x[0]):
+            return [AG.gather(x[0], self.table(rev), self.axis, self.table(not rev))], 0.
         return [ops.gather(x[0], self.table(rev), self.axis)], 0.
 
     def output_dims(self, input_dims):
@@ -66,7 +69,7 @@ class HaarTransform1D(Fm.InvertibleModule):
     def forward(self, x_in, c=None, jac=True, rev=False):
         x = x_in[0]
         ndims = x[0].numel()
-        out = ops.haar1d(x, rev)
+        out = AG.haar1d(x, rev) if AG.tracking(x) else ops.haar1d(x, rev)
         return (out,), (-ndims * self.jac_rev if rev else ndims * self.jac_fwd)
 
     def output_dims(self, input_dims):

@@ -79,8 +79,9 @@ SIGNATURES = {
     "cwfa_axpby_f32": (i, [p, p, f, f, p, i64, p]),
     "cwfa_bn_running_update_f32": (i, [p, C.c_double, f, p, p, p, i, p]),
     "cwfa_bn_finish_f32": (i, [p, d, p, p, p, f, i, p, p, f, p, p, f, f, i, p, p, i, i, p]),
-    "cwfa_chain_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), p, p, i, i, i, i, i64, i64, i64, f, f, i, p]),
-    "cwfa_chain_inv_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), i, i, i, i, i64, i64, f, i, i, p, p]),
+    "cwfa_chain_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), p, p, i, i, i, i, i64, i64, i64, f, f, i, p, p]),
+    "cwfa_affine_bwd_f32": (i, [p, p, C.POINTER(AffineStage), i, i, i, i, i, i64, i64, p, p, p, p, p]),
+    "cwfa_chain_inv_bwd_f32": (i, [p, p, C.POINTER(Chain), C.POINTER(ChainGrads), i, i, i, i, i64, i64, f, i, i, p, p, p, p]),
     "cwfa_conv2d_wgrad_workspace_bytes": (i64, [i, i, i, i, i, i]),
     "cwfa_conv2d_wgrad_f32": (i, [p, p, p, p, p, i, i, i, i, i, i, i64, i64, f, p]),
     "cwfa_elu_bwd_f32": (i, [p, p, p, p, i, i64, i64, i64, i64, i64, p]),

@@ -902,11 +902,12 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict_
                                                         cwfa_chain_grads gr, const int64_t* __restrict__ final_perm,
                                                         float* __restrict__ gv0, int C, int H, int W, int64_t z_bs,
                                                         int64_t gz_bs, int64_t gv0_bs, float gscale, float ldscale,
-                                                        int accumulate) {
+                                                        int accumulate, const float* __restrict__ gld) {
     const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = blockIdx.y;
+    if (gld) ldscale -= gld[b];              // an upstream gradient dL/d(logdet_b) (autograd): dL/ds += gld[b]
     Pos p{(int)(i / HW), (int)((i / W) % H), (int)(i % W)};
     float v = z[b * z_bs + i];
     float g = (gz ? gz[b * gz_bs + i] : 0.f) + gscale * v;
@@ -939,7 +940,8 @@ __global__ __launch_bounds__(256) void chain_bwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ gt,
                                                             cwfa_chain ch, cwfa_chain_grads gr, int C, int H, int W,
                                                             int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind,
-                                                            int accumulate, double* __restrict__ loss_sum) {
+                                                            int accumulate, double* __restrict__ loss_sum, float* __restrict__ gz_out,
+                                                            float* __restrict__ glow_out) {
     __shared__ double red[16];
     const int64_t HW = (int64_t)H * W, n = (int64_t)C * HW;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,7 +961,11 @@ __global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restr
         const float x0 = xhat[b * xhat_bs + (int64_t)(2 * p.c) * HW + pix], x1 = xhat[b * xhat_bs + (int64_t)(2 * p.c + 1) * HW + pix];
         const float d0 = x0 - gt[b * gt_bs + (int64_t)(2 * p.c) * HW + pix], d1 = x1 - gt[b * gt_bs + (int64_t)(2 * p.c + 1) * HW + pix];
         float v = (x0 - x1) * CWFA_INV_SQRT2_F, g;
-        if (loss_kind == 2) {
+        if (loss_kind == 0) {                 // `gt` IS the upstream gradient dL/dxhat (autograd)
+            const float u0 = x0 - d0, u1 = x1 - d1;
+            g = gscale * ((u0 - u1) * CWFA_INV_SQRT2_F);
+            if (glow_out) glow_out[b * n + (int64_t)p.c * HW + pix] = gscale * ((u0 + u1) * CWFA_INV_SQRT2_F);
+        } else if (loss_kind == 2) {
             g = gscale * ((d0 - d1) * CWFA_INV_SQRT2_F);
             lsum = (double)d0 * d0 + (double)d1 * d1;
         } else {
@@ -979,6 +985,7 @@ __global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restr
                 v = expf(s) * v + t;
             }
         }
+        if (gz_out) gz_out[b * n + i] = g;        // dL/d(latent input of the inverse chain), at this thread's own position
     }
     if (loss_sum) {
         const double tot = cwfa_block_sum(lsum, red);
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restr
 
 extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                                   const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream);
+                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, const float* gld, void* stream);
 
 static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds) {
     *lds = (size_t)(2 * ch->n_stages + 1) * W * sizeof(float);
@@ -1152,10 +1159,87 @@ extern "C" int cwfa_extract_views_f32(const float* image, const int* coords_yx, 
     return CWFA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ backward of ONE affine stage
+// (torch autograd of a coupling block that is not part of a fused chain: GLOW / RNVP / GIN / NICE / one-sided / AllInOne,
+//  coupling_layers.py:50-60,124-437; all_in_one_block.py:206-224).  No gather (the caller differentiates its permutation itself).
+//   rev = 0:  y = e^s x + t      dL/dx = g e^s,   dL/dt = g,         dL/ds = g e^s x + gld_b
+//   rev = 1:  y = (x - t) e^-s   dL/dx = g e^-s,  dL/dt = -g e^-s,   dL/ds = -g y - gld_b         (logdet_b = -+ sum s)
+// s = clamp(pre * s_raw) [GIN: minus its channel mean at the pixel, log-det 0], t = pre * t_raw (or -t_raw / sqrt 2).
+// One thread per pixel walks the channels (the GIN mean needs them all; the plain form just strides).
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         cwfa_affine_stage st, int rev, int C, int64_t HW, int64_t x_bs, int64_t g_bs,
+                                                         const float* __restrict__ gld, float* __restrict__ gx,
+                                                         float* __restrict__ gs, float* __restrict__ gt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)C * HW;
+    const float ld = gld ? gld[b] : 0.f;
+    float mean = 0.f, dsm = 0.f;
+    if (st.gin) {                                   // two extra sweeps: mean of s, then mean of dL/ds
+        for (int c = 0; c < C; ++c) {
+            float s, t;
+            stage_st(st, b, c * HW + i, s, t);
+            mean += s;
+        }
+        mean /= (float)C;
+        for (int c = 0; c < C; ++c) {
+            float s, t;
+            stage_st(st, b, c * HW + i, s, t);
+            s -= mean;
+            const float xv = x[b * x_bs + c * HW + i], gv = g[b * g_bs + c * HW + i];
+            dsm += rev ? -gv * ((xv - t) * expf(-s)) : gv * expf(s) * xv;
+        }
+        dsm /= (float)C;
+    }
+    for (int c = 0; c < C; ++c) {
+        const int64_t off = c * HW + i;
+        float s, t;
+        stage_st(st, b, off, s, t);
+        s -= mean;
+        const float xv = x[b * x_bs + off], gv = g[b * g_bs + off];
+        float dx, dt, ds;
+        if (!rev) {
+            const float e = expf(s);
+            dx = gv * e;
+            dt = gv;
+            ds = dx * xv + (st.gin ? 0.f : ld);
+        } else {
+            const float e = expf(-s);
+            dx = gv * e;
+            dt = -dx;
+            ds = -gv * ((xv - t) * e) - (st.gin ? 0.f : ld);
+        }
+        ds -= dsm;
+        if (gx) gx[b * n + off] = dx;
+        if (gs && st.s_raw) {
+            const float a = st.s_raw[b * st.s_bs + off] * st.pre_scale;
+            gs[b * n + off] = ds * soft_clamp_grad(a, st.clamp_kind, st.clamp) * st.pre_scale;
+        }
+        if (gt && st.t) gt[b * n + off] = st.t_neg_div_sqrt2 ? (-dt) / CWFA_SQRT2_F : dt * st.pre_scale;
+    }
+}
+
+extern "C" int cwfa_affine_bwd_f32(const float* x, const float* g, const cwfa_affine_stage* st, int rev, int B, int C, int H, int W,
+                                   int64_t x_bs, int64_t g_bs, const float* gld, float* gx, float* gs_raw, float* gt_raw, void* stream) {
+    CWFA_REQUIRE(x && g && st, CWFA_E_INVAL, "cwfa_affine_bwd_f32: null pointer");
+    CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_affine_bwd_f32: bad shape");
+    CWFA_REQUIRE(st->clamp_kind >= CWFA_CLAMP_NONE && st->clamp_kind <= CWFA_CLAMP_SIGMOID, CWFA_E_INVAL, "cwfa_affine_bwd_f32: bad clamp kind %d",
+                 st->clamp_kind);
+    CWFA_REQUIRE(!st->perm, CWFA_E_INVAL, "cwfa_affine_bwd_f32: a stage with a gather is differentiated by its caller (gather first)");
+    CWFA_REQUIRE(!st->gin || st->s_raw, CWFA_E_INVAL, "cwfa_affine_bwd_f32: GIN needs s_raw");
+    const int64_t HW = (int64_t)H * W;
+    if (B == 0 || C == 0 || HW == 0) return CWFA_OK;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, g, *st, rev, C, HW,
+                       x_bs, g_bs, gld, gx, gs_raw, gt_raw);
+    CWFA_LAUNCH_CHECK("cwfa_affine_bwd_f32");
+    return CWFA_OK;
+}
+
 static int check_chain(const char* name, const cwfa_chain* ch);
 extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                                   const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream) {
+                                  int64_t gv0_bs, float gscale, float ldscale, int accumulate, const float* gld, void* stream) {
     CWFA_REQUIRE(z && grads, CWFA_E_INVAL, "cwfa_chain_bwd_f32: null pointer");
     CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_bwd_f32: bad shape");
     int rc = check_chain("cwfa_chain_bwd_f32", ch);
@@ -1166,17 +1250,17 @@ extern "C" int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_ch
     if (B == 0 || n == 0) return CWFA_OK;
     dim3 grid((unsigned)((n + 255) / 256), B);
     hipLaunchKernelGGL(chain_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, gz, *ch, *grads, final_perm, gv0, C, H, W, z_bs,
-                       gz_bs, gv0_bs, gscale, ldscale, accumulate);
+                       gz_bs, gv0_bs, gscale, ldscale, accumulate, gld);
     CWFA_LAUNCH_CHECK("cwfa_chain_bwd_f32");
     return CWFA_OK;
 }
 
 extern "C" int cwfa_chain_inv_bwd_f32(const float* xhat, const float* gt, const cwfa_chain* ch, const cwfa_chain_grads* grads, int B,
                                       int C, int H, int W, int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind, int accumulate,
-                                      double* loss_sum, void* stream) {
+                                      double* loss_sum, float* gz_out, float* glow_out, void* stream) {
     CWFA_REQUIRE(xhat && gt && grads, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: null pointer");
     CWFA_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && B <= 65535, CWFA_E_SHAPE, "cwfa_chain_inv_bwd_f32: bad shape");
-    CWFA_REQUIRE(loss_kind == 1 || loss_kind == 2, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: loss_kind %d (1 = L1, 2 = L2)", loss_kind);
+    CWFA_REQUIRE(loss_kind >= 0 && loss_kind <= 2, CWFA_E_INVAL, "cwfa_chain_inv_bwd_f32: loss_kind %d (0 = upstream gradient, 1 = L1, 2 = L2)", loss_kind);
     int rc = check_chain("cwfa_chain_inv_bwd_f32", ch);
     if (rc) return rc;
     for (int k = 0; k < ch->n_stages; ++k)
@@ -1185,7 +1269,7 @@ extern "C" int cwfa_chain_inv_bwd_f32(const float* xhat, const float* gt, const 
     if (B == 0 || n == 0) return CWFA_OK;
     dim3 grid((unsigned)((n + 255) / 256), B);
     hipLaunchKernelGGL(chain_inv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, xhat, gt, *ch, *grads, C, H, W, xhat_bs, gt_bs,
-                       gscale, loss_kind, accumulate, loss_sum);
+                       gscale, loss_kind, accumulate, loss_sum, gz_out, glow_out);
     CWFA_LAUNCH_CHECK("cwfa_chain_inv_bwd_f32");
     return CWFA_OK;
 }

@@ -20,6 +20,7 @@ import re
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 from .FrEIA import framework as Ff
 from .FrEIA import modules as Fm
@@ -137,6 +138,13 @@ class wavelet_flow_subnetwork(nn.Module):
         ``x`` from its accumulators (ops.conv3x3_couple) instead of writing [s_raw | t]."""
         if self.conv_type is not nn.Conv2d:
             raise NotImplementedError("3-D sub-networks are not used by CWFA (every graph uses the 2-D subclasses)")
+        if couple is None and AG.tracking(u, conv_in, conv_out, self.block2, self.block4, self.block6):
+            # torch would record a graph here (training, CWFA.py:1002-1006): the whole stack as ONE autograd node whose backward is
+            # training.subnet_backward; cat(half, condition) is materialised through a differentiable concatenation
+            a = AG.subnet(self, AG.concat(list(u)) if isinstance(u, (list, tuple)) else u, conv_in, conv_out)
+            if out is not None:
+                raise NotImplementedError("wavelet_flow_subnetwork: `out=` views are an inference-path feature")
+            return a
         P = self._packed.get
         fused = self.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None
                                         for blk in (self.block2, self.block4, self.block6))
@@ -199,6 +207,8 @@ class wavelet_flow_subnetwork(nn.Module):
         mode without the split-bf16 kernel, the ``_first`` variant, more than 64 active channels) -- the caller then takes
         affine_parts + ops.affine."""
         n = x.shape[1]
+        if AG.tracking(list(parts), x, self):       # the coupling epilogue is an inference form: autograd takes affine_parts + AG.affine
+            return False
         if (not self.normal or not ops.couple_fused() or self.conv_type is not nn.Conv2d or self.c_out != 2 * n or n > 64
                 or clamp_kind is None or (max(self.n_ch, n) + 64) * x.shape[2] * x.shape[3] * 4 >= 2 ** 31):
             return False
@@ -243,6 +253,8 @@ class wavelet_flow_subnetwork(nn.Module):
             return self._stack(input, self.block12, self.block72[1])
         n = self.c_in // 2
         mean, om = input[:, :-n], input[:, -n:]
+        if AG.tracking(input, self):
+            return AG.concat([self._stack(om, self.block1, self.block7[1]), AG.neg_div_sqrt2(mean)])
         B, _, H, W = input.shape
         co = self.c_out // 2
         out = torch.empty((B, co + mean.shape[1], H, W), dtype=torch.float32, device=input.device)
@@ -305,12 +317,15 @@ class ResidualBlock(nn.Module):
         self._packed = _Packed()
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("cwfa_amd ResidualBlock: train-mode Dropout3d (p=0.5 on the hidden channels) is not "
-                                      "on the HIP path; the inverse / NLL passes run the condition nets in eval mode "
-                                      "(CWFA.py:528-529)")
         if not isinstance(self.relu, nn.PReLU) or self.relu.weight.numel() != 1:
             raise NotImplementedError("ResidualBlock activation must be a single-parameter PReLU")
+        if AG.tracking(x, self):
+            # training (CWFA.py:859,1002-1012): one autograd node; in train mode its Dropout3d draws a per-(sample, hidden channel)
+            # mask that is folded into the second Conv3d's weights (training.cond_forward_train)
+            return AG.cond_net(self, x)
+        if self.training:                         # train mode without a graph (networks.py:224: Dropout3d(0.5) is live)
+            from . import training
+            return training.cond_forward_train(self, x)[0]
         a = self.relu.weight
         P = self._packed.get
         c1, c2, ds = self.conv1[0], self.conv2[0], self.downsample[0]
@@ -411,6 +426,10 @@ class LRNN(nn.Module):
         self._packed = _Packed()
 
     def forward(self, x_in, mean_vol=None):
+        if AG.tracking(x_in, mean_vol, self):
+            # training (CWFA.py:880-886,936-950,1002-1006): the whole network as one autograd node (training.lrnn_forward_train /
+            # lrnn_backward); BatchNorm on batch statistics in train mode (CWFA.py:532), on the running ones in eval mode
+            return AG.lrnn(self, x_in, mean_vol)
         c0 = self.deconv[0]
         x = self.deconv[1](ops.conv2d(x_in, self._packed.get(c0), bias=c0.bias))
         if mean_vol is not None:

@@ -182,10 +182,32 @@ def affine(x, st_keep, rev, shape=None, logdet=None, sumsq=None, out=None):
     return out
 
 
+def affine_bwd(x, g, st_keep, rev, gld=None, want=(True, True, True)):
+    """Backward of ``affine(x, st, rev)`` for a stage without a gather: (dL/dx, dL/d s_raw, dL/d t) from g = dL/dy and the
+    upstream gradient ``gld`` [B] of the per-sample log-det; entries of ``want`` switch the three outputs."""
+    L = _lib.lib()
+    st, keep = st_keep
+    x, xbs = planes(x, "x")
+    g, gbs = planes(g, "g")
+    B, Cc, H, W = x.shape
+    if tuple(g.shape) != (B, Cc, H, W):
+        raise ValueError("affine_bwd: g and x differ in shape")
+    mk = lambda on: torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device) if on else None    # noqa: E731
+    gx, gs, gt = mk(want[0]), mk(want[1] and bool(st.s_raw)), mk(want[2] and bool(st.t))
+    if gld is not None:
+        gld = _dev(gld, "gld").contiguous()
+    check(L.cwfa_affine_bwd_f32(_p(x), _p(g), C.byref(st), int(bool(rev)), B, Cc, H, W, xbs, gbs, _p(gld), _p(gx), _p(gs), _p(gt),
+                                _stream()), "affine_bwd")
+    return gx, gs, gt
+
+
 def channel_affine(x, scale, shift, inverse=False, perm_in=None, perm_out=None):
     L = _lib.lib()
     x, xbs = planes(x, "x")
     B, Cc, H, W = x.shape
+    for t in (scale, shift, perm_in, perm_out):
+        if t is not None and t.numel() != Cc:
+            raise ValueError("channel_affine: scale / shift / permutation tables must hold one entry per channel")
     out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     check(L.cwfa_channel_affine_f32(_p(x), _p(out), _p(scale), _p(shift), int(bool(inverse)), _p(_idx(perm_in)),
                                     _p(_idx(perm_out)), B, Cc, H * W, xbs, Cc * H * W, _stream()), "channel_affine")
@@ -292,9 +314,11 @@ def _chain_grads(grads, shape):
     return gr
 
 
-def chain_inv_bwd(xhat, gt, stages, grads, gscale, loss_kind=2, accumulate=False):
+def chain_inv_bwd(xhat, gt, stages, grads, gscale, loss_kind=2, accumulate=False, want_latent_grad=False, want_low_grad=False):
     """Backward of gscale-weighted sum |xhat - gt|^p (p = loss_kind) through the inverse pass that produced ``xhat``;
-    ``stages`` in FORWARD order.  Returns the float64[1] tensor sum |xhat - gt|^p."""
+    ``stages`` in FORWARD order.  ``loss_kind`` 0: ``gt`` IS an upstream gradient dL/dxhat (times gscale).  Returns the float64[1]
+    tensor sum |xhat - gt|^p -- or, with ``want_latent_grad`` / ``want_low_grad``, the tuple (sum, dL/dz, dL/dlow) of the inverse
+    pass's two inputs (None where not wanted; dL/dlow needs loss_kind 0)."""
     L = _lib.lib()
     xhat, xbs = planes(xhat, "xhat")
     gt, gbs = planes(gt, "gt")
@@ -305,12 +329,18 @@ def chain_inv_bwd(xhat, gt, stages, grads, gscale, loss_kind=2, accumulate=False
     ch, keep = _chain(stages)
     gr = _chain_grads(grads, (B, Cc, H, W))
     loss = torch.zeros(1, dtype=torch.float64, device=xhat.device)
+    if want_low_grad and loss_kind != 0:
+        raise ValueError("chain_inv_bwd: dL/dlow is formed from an upstream gradient (loss_kind 0)")
+    gz = torch.empty((B, Cc, H, W), dtype=torch.float32, device=xhat.device) if want_latent_grad else None
+    glow = torch.empty((B, Cc, H, W), dtype=torch.float32, device=xhat.device) if want_low_grad else None
     check(L.cwfa_chain_inv_bwd_f32(_p(xhat), _p(gt), C.byref(ch), C.byref(gr), B, Cc, H, W, xbs, gbs, float(gscale), int(loss_kind),
-                                   int(bool(accumulate)), _p(loss), _stream()), "chain_inv_bwd")
+                                   int(bool(accumulate)), _p(loss), _p(gz), _p(glow), _stream()), "chain_inv_bwd")
+    if want_latent_grad or want_low_grad:
+        return loss, gz, glow
     return loss
 
 
-def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=None, want_input_grad=False, accumulate=False):
+def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=None, want_input_grad=False, accumulate=False, gld=None):
     """Backward of L = gscale*0.5*sum z^2 - ldscale*sum logdet (+ <gz, z>) through the chain that produced ``z``
     (``chain_fwd`` with the same ``stages`` / ``final_perm``).  ``grads[k] = (ds_raw_k, dt_k)``: preallocated
     [B,C,H,W] views (contiguous planes) or None.  Returns dL/d(detail band) if ``want_input_grad``."""
@@ -323,8 +353,12 @@ def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=Non
     if gz is not None:
         gz, gzbs = planes(gz, "gz")
     gv0 = torch.empty((B, Cc, H, W), dtype=torch.float32, device=z.device) if want_input_grad else None
+    if gld is not None:                      # upstream gradient of the per-sample log-det (autograd)
+        gld = _dev(gld, "gld").contiguous()
+        if gld.numel() != B:
+            raise ValueError("chain_bwd: gld must hold one value per sample")
     check(L.cwfa_chain_bwd_f32(_p(z), _p(gz), C.byref(ch), C.byref(gr), _p(_idx(final_perm)), _p(gv0), B, Cc, H, W, zbs, gzbs,
-                               Cc * H * W, float(gscale), float(ldscale), int(bool(accumulate)), _stream()), "chain_bwd")
+                               Cc * H * W, float(gscale), float(ldscale), int(bool(accumulate)), _p(gld), _stream()), "chain_bwd")
     return gv0
 
 
@@ -690,6 +724,8 @@ def elu_bwd(g, a, add=None, out=None):
     a, abs_ = planes(a, "a")
     B = g.shape[0]
     n = g[0].numel()
+    if tuple(a.shape) != tuple(g.shape) or (add is not None and tuple(add.shape) != tuple(g.shape)):
+        raise ValueError("elu_bwd: g, a (and add) differ in shape")
     addbs = 0
     if add is not None:
         add, addbs = planes(add, "add")
@@ -716,6 +752,8 @@ def plane_affine(x, scale=None, shift=None, add=None):
     abs_ = 0
     if add is not None:
         add, abs_ = planes(add, "add")
+        if tuple(add.shape) != (B, Cc, H, W):       # (a centre-cropped skip of another size: the reference's `up + crop` raises too)
+            raise ValueError(f"plane_affine: add {tuple(add.shape)} does not match x {(B, Cc, H, W)}")
     out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
     check(L.cwfa_plane_affine_f32(_p(x), _p(scale), _p(shift), per, _p(add), _p(out), B, Cc, H * W, xbs, abs_, Cc * H * W, _stream()),
           "plane_affine")
@@ -728,6 +766,8 @@ def bn_bwd_stats(g, y, mask_bc=None):
     g, gbs = planes(g, "g")
     y, ybs = planes(y, "y")
     B, Cc, H, W = g.shape
+    if tuple(y.shape) != (B, Cc, H, W) or (mask_bc is not None and mask_bc.numel() != B * Cc):
+        raise ValueError(f"bn_bwd_stats: g {tuple(g.shape)}, y {tuple(y.shape)} / mask do not match")
     st = torch.zeros(2 * Cc, dtype=torch.float64, device=g.device)
     check(L.cwfa_bn_bwd_stats_f32(_p(g), _p(y), _p(None if mask_bc is None else _dev(mask_bc).contiguous()), _p(st), B, Cc, H * W, gbs,
                                   ybs, _stream()), "bn_bwd_stats")
@@ -741,6 +781,8 @@ def bn_act_bwd(g, y, A, Bc, Cc_, alpha=None, dalpha=None, out=None):
     y, ybs = planes(y, "y")
     B, Cc, H, W = g.shape
     A = _dev(A).contiguous()
+    if tuple(y.shape) != (B, Cc, H, W) or A.numel() not in (Cc, B * Cc) or Bc.numel() != Cc or Cc_.numel() != Cc:
+        raise ValueError(f"bn_act_bwd: g {tuple(g.shape)}, y {tuple(y.shape)} or the coefficient tables do not match")
     per = int(A.numel() == B * Cc and B > 1)
     if out is None:
         out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
@@ -758,8 +800,12 @@ def maxpool2_bwd(full, g_pool, g_skip=None):
     full = _dev(full, "full").contiguous()
     g_pool = _dev(g_pool, "g_pool").contiguous()
     B, Cc, H, W = full.shape
+    if tuple(g_pool.shape) != (B, Cc, H // 2, W // 2):
+        raise ValueError(f"maxpool2_bwd: g_pool {tuple(g_pool.shape)} is not the 2x2-pooled shape of {tuple(full.shape)}")
     if g_skip is not None:
         g_skip = _dev(g_skip, "g_skip").contiguous()
+        if tuple(g_skip.shape) != tuple(full.shape):
+            raise ValueError("maxpool2_bwd: g_skip and full differ in shape")
     out = torch.empty_like(full)
     check(L.cwfa_maxpool2_bwd_f32(_p(full), _p(g_pool), _p(g_skip), _p(out), B, Cc, H, W, _stream()), "maxpool2_bwd")
     return out
@@ -770,6 +816,8 @@ def gelu_add(p, res=None):
     L = _lib.lib()
     p = _dev(p, "p").contiguous()
     res = None if res is None else _dev(res).contiguous()
+    if res is not None and tuple(res.shape) != tuple(p.shape):
+        raise ValueError("gelu_add: p and res differ in shape")
     out = torch.empty_like(p)
     check(L.cwfa_gelu_f32(_p(p), _p(res), _p(out), p.numel(), 0, _stream()), "gelu")
     return out
@@ -778,6 +826,8 @@ def gelu_add(p, res=None):
 def gelu_bwd(g, p):
     L = _lib.lib()
     p, g = _dev(p, "p").contiguous(), _dev(g, "g").contiguous()
+    if tuple(g.shape) != tuple(p.shape):
+        raise ValueError("gelu_bwd: g and p differ in shape")
     out = torch.empty_like(p)
     check(L.cwfa_gelu_f32(_p(p), _p(g), _p(out), p.numel(), 1, _stream()), "gelu_bwd")
     return out
@@ -788,6 +838,8 @@ def layernorm_bwd(g, v, weight, mean, invstd, dw, db):
     L = _lib.lib()
     g, v = _dev(g, "g").contiguous(), _dev(v, "v").contiguous()
     B, n = v.shape[0], v[0].numel()
+    if tuple(g.shape) != tuple(v.shape) or weight.numel() != n or mean.numel() != B or invstd.numel() != B or dw.numel() != n or db.numel() != n:
+        raise ValueError("layernorm_bwd: operand shapes do not match")
     st = torch.zeros(2 * B, dtype=torch.float64, device=v.device)
     gv = torch.empty_like(v)
     check(L.cwfa_layernorm_bwd_f32(_p(g), _p(v), _p(_dev(weight).contiguous()), _p(_dev(mean).contiguous()), _p(_dev(invstd).contiguous()),
@@ -799,6 +851,8 @@ def attention_bwd(mean, w1, b1, w2, b2, m, g):
     """Backward of ``attention_combine(mean, ..., m, x)`` given g = dL/dout: (dL/dm, float64 [w1|b1|w2|b2] gradients); dL/dx = g."""
     L = _lib.lib()
     mean, m, g = _dev(mean).contiguous(), _dev(m).contiguous(), _dev(g).contiguous()
+    if tuple(m.shape) != tuple(mean.shape) or tuple(g.shape) != tuple(mean.shape):
+        raise ValueError("attention_bwd: mean, m and g differ in shape")
     B, Cc = mean.shape[:2]
     HW = mean[0, 0].numel()
     gm = torch.empty_like(m)
@@ -813,6 +867,8 @@ def prelu_bwd(g, o, alpha, dalpha=None, out=None):
     L = _lib.lib()
     g, gbs = planes(g, "g")
     o, obs = planes(o, "o")
+    if tuple(o.shape) != tuple(g.shape):
+        raise ValueError("prelu_bwd: g and o differ in shape")
     B, n = g.shape[0], g[0].numel()
     if out is None:
         out = torch.empty(tuple(g.shape), dtype=torch.float32, device=g.device)
@@ -937,6 +993,9 @@ def maxpool(x, Ho, Wo, scale=None, shift=None, want_full=False):
     L = _lib.lib()
     x = _dev(x, "x").contiguous()
     B, Cc, H, W = x.shape
+    for t in (scale, shift):
+        if t is not None and t.numel() != Cc:
+            raise ValueError("maxpool: the load-side affine must be a [C] table")
     y = torch.empty((B, Cc, Ho, Wo), dtype=x.dtype, device=x.device)
     full = torch.empty_like(x) if want_full else None
     check(L.cwfa_maxpool_f32(_p(x), _p(y), _p(full), _p(scale), _p(shift), B, Cc, H, W, Ho, Wo, _stream()), "maxpool")
@@ -955,6 +1014,8 @@ def sample_stats(x):
 def layernorm_apply(x, stats, weight, bias, eps):
     L = _lib.lib()
     x = _dev(x, "x").contiguous()
+    if stats.numel() != 2 * x.shape[0] or weight.numel() != x[0].numel() or bias.numel() != x[0].numel():
+        raise ValueError("layernorm_apply: statistics / affine do not match x")
     out = torch.empty_like(x)
     check(L.cwfa_layernorm_apply_f32(_p(x), _p(stats), _p(weight), _p(bias), float(eps), _p(out), x.shape[0],
                                      x[0].numel(), _stream()), "layernorm_apply")
@@ -969,6 +1030,11 @@ def attention_combine(mean, w1, b1, w2, b2, m=None, x=None):
     out = torch.empty_like(mean)
     m = None if m is None else _dev(m).contiguous()
     x = None if x is None else _dev(x).contiguous()
+    for t in (m, x):
+        if t is not None and tuple(t.shape) != tuple(mean.shape):
+            raise ValueError("attention_combine: mean, m and x must share one shape")
+    if w1.numel() != Cc * Cc * 3 or b1.numel() != Cc or w2.numel() != Cc * Cc or b2.numel() != Cc:
+        raise ValueError("attention_combine: the Conv1d banks do not match the channel count")
     check(L.cwfa_attention_combine_f32(_p(mean), _p(_dev(w1).contiguous()), _p(_dev(b1)), _p(_dev(w2).contiguous()),
                                        _p(_dev(b2)), _p(m), _p(x), _p(out), B, Cc, HW, _stream()), "attention_combine")
     return out
@@ -978,6 +1044,8 @@ def scale_channels(x, scale_bc):
     L = _lib.lib()
     x = _dev(x, "x").contiguous()
     B, Cc = x.shape[:2]
+    if scale_bc.numel() != B * Cc:
+        raise ValueError(f"scale_channels: the table must hold B*C = {B * Cc} factors")
     out = torch.empty_like(x)
     check(L.cwfa_scale_channels_f32(_p(x), _p(_dev(scale_bc).contiguous()), _p(out), B, Cc, x[0, 0].numel(), _stream()),
           "scale_channels")
@@ -988,6 +1056,8 @@ def axpby(x, a, z=None, b=0.0):
     L = _lib.lib()
     x = _dev(x, "x").contiguous()
     z = None if z is None else _dev(z).contiguous()
+    if z is not None and z.numel() != x.numel():
+        raise ValueError("axpby: x and z differ in size")
     out = torch.empty_like(x)
     check(L.cwfa_axpby_f32(_p(x), _p(z), float(a), float(b), _p(out), x.numel(), _stream()), "axpby")
     return out

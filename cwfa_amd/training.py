@@ -259,7 +259,7 @@ def cond_forward_train(cond_net, views, drop_mask=None):
     mask).  Dropout3d zeroes whole hidden channels per sample and the second Conv3d is linear in them, so the mask is
     FOLDED INTO THAT CONV'S WEIGHTS per sample, w2[b, k] = mask[b, k] * w2[k]: the fused 1 -> K -> 1 kernel and its backward
     run unchanged, one launch per sample."""
-    blk = cond_net.subnetworks[0]
+    blk = cond_net.subnetworks[0] if hasattr(cond_net, "subnetworks") else cond_net      # a cond_network or its ResidualBlock
     a = blk.relu.weight
     P = blk._packed.get
     c1, c2, ds = blk.conv1[0], blk.conv2[0], blk.downsample[0]
@@ -333,7 +333,7 @@ def cond_backward(tape, g_omega):
 # UNet of the LRNN (unet.py:72-113,161-195), train-mode BatchNorm (CWFA.py:532)
 # ---------------------------------------------------------------------------------------------------------------------
 class _LayerRec:
-    __slots__ = ("conv", "alpha", "bn", "u", "y", "mean", "invstd", "mask", "n")
+    __slots__ = ("conv", "alpha", "bn", "u", "y", "mean", "invstd", "mask", "n", "batch_stats")
 
 
 def _prelu_of(act):
@@ -360,18 +360,24 @@ def _block_forward_train(block, u, out_mask):
         m = out_mask if li == len(layers) - 1 else None
         Cc = y.shape[1]
         n = y.numel() // Cc
-        st = ops.channel_stats(y)
-        if bn.track_running_stats and bn.momentum is not None:
-            ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
-        sv = st.view(Cc, 2)
-        mean = sv[:, 0] / n
-        invstd = torch.rsqrt(sv[:, 1] / n - mean * mean + bn.eps)
+        batch_stats = bn.training or not bn.track_running_stats
+        if batch_stats:
+            st = ops.channel_stats(y)
+            if bn.track_running_stats and bn.momentum is not None:
+                ops.bn_running_update(st, n, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            sv = st.view(Cc, 2)
+            mean = sv[:, 0] / n
+            invstd = torch.rsqrt(sv[:, 1] / n - mean * mean + bn.eps)
+        else:                                   # eval mode: the running statistics are constants of the graph
+            mean = bn.running_mean.detach().double()
+            invstd = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
         scale = bn.weight.detach().double() * invstd
         shift = bn.bias.detach().double() - mean * scale
         if m is not None:
             scale, shift = m.double() * scale[None, :], m.double() * shift[None, :]
         r = _LayerRec()
         r.conv, r.alpha, r.bn, r.u, r.y, r.mean, r.invstd, r.mask, r.n = conv, alpha, bn, u, y, mean, invstd, m, n
+        r.batch_stats = batch_stats
         recs.append(r)
         u = ops.plane_affine(y, scale.float(), shift.float())
     return u, recs
@@ -385,8 +391,12 @@ def _block_backward(recs, g):
         s2h = (s2 - r.mean * s1) * r.invstd                        # sum g m xhat
         k = r.bn.weight.detach().double() * r.invstd
         A = k if r.mask is None else r.mask.double() * k[None, :]
-        Cc = -k * r.invstd * s2h / r.n
-        Bc = -k * s1 / r.n - Cc * r.mean
+        if r.batch_stats:
+            Cc = -k * r.invstd * s2h / r.n
+            Bc = -k * s1 / r.n - Cc * r.mean
+        else:                                   # running statistics: a fixed per-channel affine, no statistics terms
+            Cc = torch.zeros_like(k)
+            Bc = torch.zeros_like(k)
         _acc(r.bn.weight, s2h)
         _acc(r.bn.bias, s1)
         dalpha = torch.zeros(1, dtype=torch.float64, device=g.device)

@@ -388,19 +388,28 @@ typedef struct {
 /* L = gscale * 0.5 * sum z^2 - ldscale * sum_b logdet_b (+ <gz, z> for an upstream gradient gz, nullable), z the output
  * of cwfa_chain_fwd_f32 with the same chain / final_perm.  No stored activations: every stage input is recomputed by
  * inverting the stage.  gv0 (nullable) receives dL/d(detail band entering the chain).  accumulate != 0: the stage
- * gradients are ADDED to the buffers. */
+ * gradients are ADDED to the buffers.  gld (nullable, float[B]): an upstream gradient dL/d(logdet_b) per sample, added to the
+ * uniform -ldscale (what torch autograd hands the backward of `log_jac_det.mean()`, CWFA.py:978). */
 int cwfa_chain_bwd_f32(const float* z, const float* gz, const cwfa_chain* ch, const cwfa_chain_grads* grads,
                        const int64_t* final_perm, float* gv0, int B, int C, int H, int W, int64_t z_bs, int64_t gz_bs,
-                       int64_t gv0_bs, float gscale, float ldscale, int accumulate, void* stream);
+                       int64_t gv0_bs, float gscale, float ldscale, int accumulate, const float* gld, void* stream);
 
 /* Backward of the reconstruction term (CWFA.py:952-959: F.l1_loss / F.mse_loss(curr_gt, upsampled_vol)) through the
  * INVERSE pass xhat = cwfa_chain_inv_f32(z, low, ...) (CWFA.py:911): L = gscale' * sum |xhat - gt|^p, p = loss_kind
  * (1: gscale = weight/numel, 2: gscale = 2*weight/numel).  `ch` is the FORWARD-order chain (as for cwfa_chain_fwd_f32);
  * the gradients go to the same buffers as cwfa_chain_bwd_f32's (accumulate != 0: added) since both passes use the same
- * coefficients.  loss_sum (nullable, double[1]) += sum |xhat - gt|^p.  No stored activations. */
+ * coefficients.  loss_sum (nullable, double[1]) += sum |xhat - gt|^p.  No stored activations.
+ * loss_kind = 0: `gt` holds an upstream gradient dL/dxhat itself (torch autograd; scaled by gscale).  gz_out / glow_out
+ * (nullable, contiguous [B,C,H,W]): dL/d(latent input z) and, for loss_kind 0, dL/d(low) of the inverse pass. */
 int cwfa_chain_inv_bwd_f32(const float* xhat, const float* gt, const cwfa_chain* ch, const cwfa_chain_grads* grads, int B, int C,
                            int H, int W, int64_t xhat_bs, int64_t gt_bs, float gscale, int loss_kind, int accumulate,
-                           double* loss_sum, void* stream);
+                           double* loss_sum, float* gz_out, float* glow_out, void* stream);
+
+/* Backward of ONE affine stage y = cwfa_affine_f32(x, st, rev) without a gather (torch autograd of the coupling blocks that are
+ * not part of a fused chain: coupling_layers.py:124-437, all_in_one_block.py:206-224): g = dL/dy, gld (nullable, float[B]) =
+ * dL/d(logdet_b); writes dL/dx, dL/d s_raw, dL/d t (each nullable, contiguous [B,C,H,W]).  GIN stages included. */
+int cwfa_affine_bwd_f32(const float* x, const float* g, const cwfa_affine_stage* st, int rev, int B, int C, int H, int W,
+                        int64_t x_bs, int64_t g_bs, const float* gld, float* gx, float* gs_raw, float* gt_raw, void* stream);
 
 /* Weight gradient of a stride-1, zero-padded ("same") convolution, ks = 1 or 3, on the fp32 matrix cores:
  *   dw[co][ci][ky][kx] = beta * dw + sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+ky-ks/2][x+kx-ks/2]     (torch layout)

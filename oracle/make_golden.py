@@ -24,6 +24,7 @@ Fixture index:
   g11_unet_*, g11_convnext, g11_attention, g11_lrnn_small, g11_lrnn_full
   g12_extract_views_*   XLFMDatasetFull.extract_views (needs only torch: imported from the reference file directly)
   g13_step_grad_*       autograd gradients of the training NLL of one CAT step (CWFA.py:966-978,1002-1006)
+  g20_blockgrad_*       the same for steps built with the data-dependent block types (GLOW, AI1, RNVP, GIN)
   g14_unet_grad_*       autograd gradients of the UNet in train mode (unet.py:72-113,161-195)
   g15_meanbranch_grad   autograd gradients of the LRNN's mean-volume branch (networks.py:468-503,244-262,552-554)
   g16_concat            Concat fwd / rev, three inputs              (graph_topology.py:92-152)
@@ -598,6 +599,52 @@ def gen_step_grad():
              n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))
 
 
+def gen_block_grad():
+    """g20: the default training loss of a flow step built with the DATA-DEPENDENT block types (main.py --INN_block_type: GLOW, AI1,
+    RNVP, GIN): 0.40984 * mse(gt, xhat) + 0.59016 * NLL with xhat from the inverse pass on a sampled z (CWFA.py:905-911,
+    952-987), forward values and the gradient of every parameter and of both conditions from the reference's own graph + torch
+    autograd (coupling_layers.py:124-437, all_in_one_block.py:206-268 under `full_loss.backward()`, CWFA.py:1002-1006)."""
+    Ff, Fm, INN_utils, networks, unet, CWFA = import_reference()
+    fresh_process_state(networks)
+    import torch
+    import torch.nn.functional as F
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(2020)
+    S, D, H, W, ix, n_ch, B = 3, 16, 12, 16, 0, 8, 2
+    for bt in ("GLOW", "AI1", "RNVP", "GIN"):
+        torch.manual_seed(400 + len(bt))
+        np.random.seed(11)
+        networks.networks_n_chans = n_ch
+        Cn = D // 2 ** (ix + 1)
+        cond_net, inns = networks.conditional_wavelet_flow(
+            [D, H, W], [1, 29, H, W], networks.wavelet_flow_subnetwork2D,
+            lambda: networks.cond_network(29, Cn, ix + 1, S, [], 4),
+            n_internal_ch=n_ch, n_down_steps=ix + 1, use_permutations=True, block_type=bt, n_blocks=4)
+        inn = inns[ix].train()
+        with torch.no_grad():
+            for p in inn.parameters():
+                if p.requires_grad and p.dtype == torch.float32:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        meta = {}
+        for i, mdl in enumerate(inn.module_list):
+            if type(mdl).__name__ == "PermuteDim":
+                meta[f"meta/axis_{i}"] = np.int64(mdl.dims_to_permute[1])
+        x = torch.randn(B, D, H, W, generator=g)
+        c = [torch.randn(B, Cn, H, W, generator=g).requires_grad_(), (0.3 * torch.randn(B, Cn, H, W, generator=g)).requires_grad_()]
+        z_in = 0.5 * torch.randn(B, Cn, H, W, generator=g)
+        low_in = torch.randn(B, Cn, H, W, generator=g)
+        w_c = 0.40984
+        xhat, _ = inn([z_in, low_in], c=c, rev=True)
+        Z, ld = inn(x, c=c)
+        nll = (0.5 * torch.norm(Z[0]) ** 2 - ld.mean()) / xhat.numel()
+        full = w_c * F.mse_loss(x, xhat) + (1 - w_c) * nll
+        full.backward()
+        grads = {"grad/" + k: npy(p.grad) for k, p in inn.named_parameters() if p.grad is not None}
+        dump(f"g20_blockgrad_{bt}", x=npy(x), c0=npy(c[0]), c1=npy(c[1]), z_in=npy(z_in), low_in=npy(low_in), xhat=npy(xhat), z=npy(Z[0]),
+             low=npy(Z[1]), logdet=npy(ld), loss=np.float64(full.item()), nll=np.float64(nll.item()), w_c=np.float64(w_c),
+             gc0=npy(c[0].grad), gc1=npy(c[1].grad), ix=np.int64(ix), n_ch=np.int64(n_ch), **meta, **grads, **sd_arrays(inn))
+
+
 def gen_unet_grad():
     """g14: gradients of every UNet parameter (and of its input) in train mode -- batch-statistics BatchNorm, PReLU,
     max-pool, skip additions, transposed convolutions (unet.py:72-113,161-195) -- from the reference's own modules and
@@ -667,6 +714,8 @@ if __name__ == "__main__":
         gen_extract_views()
     elif len(sys.argv) > 1 and sys.argv[1] == "step_grad":
         gen_step_grad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "block_grad":
+        gen_block_grad()
     elif len(sys.argv) > 1 and sys.argv[1] == "topology":
         gen_topology()
     elif len(sys.argv) > 1 and sys.argv[1] == "ai1_options":
@@ -680,5 +729,6 @@ if __name__ == "__main__":
         gen_cache_and_output()
         gen_extract_views()
         gen_step_grad()
+        gen_block_grad()
         gen_unet_grad()
         gen_meanbranch_grad()

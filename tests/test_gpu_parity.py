@@ -547,6 +547,7 @@ def _step(name, fx):
 
 @pytest.mark.parametrize("name", [n for n in names("g04_") if n.split("_")[1] in ("GLOW", "ONESIDED")] + names("g05_ai1_gin0") +
                          [n for n in names("g09_") if "GLOW" in n or "AI1" in n])
+@torch.no_grad()            # the fused epilogue is the INFERENCE form; with a graph being recorded the blocks take cwfa_amd.autograd's nodes
 def test_coupling_in_the_conv_epilogue_golden(name, monkeypatch):
     """Split precision: the last convolution of the sub-network applies the coupling from its accumulators (s, t never reach
     memory; cwfa_conv3x3_split_couple_f32) -- same golden vectors, same bound as the unfused path."""
