@@ -30,8 +30,41 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef C3S_SGB
 #define C3S_SGB 0
 #endif
+// measured on one box, all four condition-net sizes (tools/c3s_tune.py): plain 0.954 - 0.979 ms, software pipeline over the columns
+// with a 1 MFMA : 2 VALU scheduling pattern 0.951, + waves 4..7 doing the side work mid-step 0.930
+#ifndef C3S_STAGGER
+#define C3S_STAGGER 1
+#endif
+#ifndef C3S_PIPE
+#define C3S_PIPE 2
+#endif
+#ifndef C3S_PRIO
+#define C3S_PRIO 0
+#endif
+#ifndef C3S_STAMP
+#define C3S_STAMP 0
+#endif
+#ifndef C3S_ABL
+#define C3S_ABL 0          // (timing ablations only, results wrong) 1: no conv1 MFMAs, 2: no conv2 MFMAs, 4: no residual split, 8: no side work, 16: no B1 gather
+#endif
 
 extern int g_cwfa_split_products;       // conv2d.hip ("split_products" option: 6 or 1)
+
+#if C3S_STAMP
+// diagnostic build only (tools/c3s_tune.py): s_memtime stamps of block 300's waves 0 and 4 at the section borders of steps 10..13;
+// never compiled into the library
+__device__ unsigned long long g_c3s_stamps[2 * 4 * 16];
+extern "C" int cwfa_dbg_c3s_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c3s_stamps), sizeof(g_c3s_stamps));
+}
+#define STAMP(k)                                                                                                     \
+    do {                                                                                                             \
+        if (blockIdx.x == 300 && blockIdx.y == 0 && (wave == 0 || wave == 4) && lane == 0 && s >= 10 && s < 14)      \
+            g_c3s_stamps[((wave >> 2) * 4 + (s - 10)) * 16 + (k)] = __builtin_readcyclecounter();                  \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
 
 namespace {
 
@@ -241,6 +274,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) ring[s][c] = zero4;
 
+#if C3S_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(C3S_PRIO);      // the younger SIMD partner loses every arbitration otherwise
+#endif
     // ---- prologue: x slabs 0, 1, 2 of the chunk into ring slots 0..2, slab 3 in flight
     load_x(0);
     store_x(0);
@@ -289,9 +325,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
         constexpr bool EDGE = decltype(edge)::value != 0;
         constexpr int S0 = PH, S1 = (PH + 2) % 3, S2 = (PH + 1) % 3;     // slots of output slabs d' + 1, d', d' - 1
         const int dp = d0 - 1 + s;
-        if (s >= 3 && tid < C::NOUT) gather(d0 + s - 3, (s - 1) & 1);
-        store_x((s + 3) & 3);
-        load_x(s + 4);
+        // the per-step side work (output gather of the slab completed a step ago, x slab into the ring, next slab's loads).  Waves
+        // 4..7 -- the SIMD partners of waves 0..3 -- do it in the MIDDLE of their four columns (C3S_STAGGER): partners that run the
+        // same stream in phase reach their vector-heavy and their matrix-heavy parts together
+        auto side_work = [&]() {
+            if (s >= 3 && tid < C::NOUT) gather(d0 + s - 3, (s - 1) & 1);
+            store_x((s + 3) & 3);
+            load_x(s + 4);
+        };
+        const bool late = C3S_STAGGER && !EDGE && wave >= 4;
+        STAMP(0);
+        if (!late && !(C3S_ABL & 8)) side_work();
+        STAMP(1);
         const bool do2 = s >= 2;
         const bool slab_in = dp >= 0 && dp < p.D;
         int a[8];
@@ -304,10 +349,79 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
         }
         if constexpr (!EDGE) {
             if (slab_in) {
+#if C3S_PIPE
+                // software pipeline over the wave's four columns: region X_c = { PReLU + split of column c (vector) | conv1 of column
+                // c + 1 and conv2 of column c - 1 (matrix) }: independent instruction streams the scheduler can interleave
+                u32x2 e[2][8];
+                bf16x8 B1[NQ], B2[2][NQ];
+                f32x4 hd[2][2];
+                if (C3S_ABL & 16) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[0][j] = e[1][j] = u32x2{(unsigned)a[j], (unsigned)laneoff[j]};
+                } else {
+                rd_b1(e[0], a, 0);
+                rd_b1(e[1], a, 1);
+                }
+                STAMP(2);
+                mk_b1(e[0], B1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) hd[0][t] = (C3S_ABL & 1) ? bias1[t] + __builtin_bit_cast(f32x4, B1[0]).xxxx : mfma6<SIX>(bias1[t], A1[t], B1);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(3);
+#pragma unroll
+                for (int col = 0; col < NCOL; ++col) {
+                    if (col == NCOL / 2 && late && !(C3S_ABL & 8)) side_work();
+                    float hv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[j] = __builtin_amdgcn_fmed3f(hd[col & 1][j >> 2][j & 3], alpha * hd[col & 1][j >> 2][j & 3], prelu_m);
+                    if (C3S_ABL & 4) {
+                        bf16x8 one[1];
+                        pack8<false>(hv, one);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) B2[col & 1][q] = one[0];
+                    } else {
+                        pack8<SIX>(hv, B2[col & 1]);
+                    }
+                    if (col + 1 < NCOL) {
+                        mk_b1(e[(col + 1) & 1], B1);
+                        if (col + 2 < NCOL && !(C3S_ABL & 16)) rd_b1(e[col & 1], a, col + 2);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) hd[(col + 1) & 1][t] = (C3S_ABL & 1) ? bias1[t] + __builtin_bit_cast(f32x4, B1[0]).xxxx : mfma6<SIX>(bias1[t], A1[t], B1);
+                    }
+                    if (col > 0) {
+                        if (C3S_ABL & 2) {
+                            ring[S0][col - 1] = __builtin_bit_cast(f32x4, B2[(col - 1) & 1][0]);
+                            ring[S1][col - 1] += __builtin_bit_cast(f32x4, B2[(col - 1) & 1][NQ - 1]);
+                        } else {
+                        ring[S0][col - 1] = mfma6<SIX>(zero4, A2[0], B2[(col - 1) & 1]);
+                        ring[S1][col - 1] = mfma6<SIX>(ring[S1][col - 1], A2[1], B2[(col - 1) & 1]);
+                        ring[S2][col - 1] = mfma6<SIX>(ring[S2][col - 1], A2[2], B2[(col - 1) & 1]);
+                        }
+                    }
+#if C3S_PIPE > 1
+#pragma unroll
+                    for (int i = 0; i < (SIX ? 30 : 5); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, C3S_PIPE, 0);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    STAMP(4 + col);
+                }
+                if (C3S_ABL & 2) {
+                    ring[S0][NCOL - 1] = __builtin_bit_cast(f32x4, B2[(NCOL - 1) & 1][0]);
+                    ring[S1][NCOL - 1] += __builtin_bit_cast(f32x4, B2[(NCOL - 1) & 1][NQ - 1]);
+                } else {
+                ring[S0][NCOL - 1] = mfma6<SIX>(zero4, A2[0], B2[(NCOL - 1) & 1]);
+                ring[S1][NCOL - 1] = mfma6<SIX>(ring[S1][NCOL - 1], A2[1], B2[(NCOL - 1) & 1]);
+                ring[S2][NCOL - 1] = mfma6<SIX>(ring[S2][NCOL - 1], A2[2], B2[(NCOL - 1) & 1]);
+                }
+#else
                 u32x2 e[2][8];
                 rd_b1(e[0], a, 0);
 #pragma unroll
                 for (int col = 0; col < NCOL; ++col) {
+                    if (col == NCOL / 2 && late) side_work();
                     if (col + 1 < NCOL) rd_b1(e[(col + 1) & 1], a, col + 1);
                     bf16x8 B1[NQ], B2[NQ];
                     mk_b1(e[col & 1], B1);
@@ -322,15 +436,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
                     ring[S1][col] = mfma6<SIX>(ring[S1][col], A2[1], B2);
                     ring[S2][col] = mfma6<SIX>(ring[S2][col], A2[2], B2);
                 }
-#if C3S_SGB > 0
-                // scheduling pipeline over the four columns: one MFMA, then C3S_SGB vector instructions, ...
-#pragma unroll
-                for (int i = 0; i < NCOL * (SIX ? 30 : 5); ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, C3S_SGB, 0);
-                }
 #endif
             } else {
+                if (late) side_work();
 #pragma unroll
                 for (int col = 0; col < NCOL; ++col) ring[S0][col] = zero4;
             }
@@ -366,6 +474,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
                 }
             }
         }
+        STAMP(8);
         if (do2 && g < 3) {                   // output slab d' - 1 is complete: G'[dh = g][dw = r] of this wave's rows
             const int buf = s & 1;
 #pragma unroll
@@ -376,7 +485,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_kernel(P3 p) {
                     for (int r = 0; r < 3; ++r)
                         *reinterpret_cast<float*>(lds + g_wr + buf * C::GB + r * C::GPS + rr * C::GROW + nt * 64) = ring[S2][rr * C::NTW + nt][r];
         }
+        STAMP(9);
         lds_barrier();
+        STAMP(10);
     };
 
     // interior blocks: every hidden row and column of the tile lies inside the image

@@ -741,6 +741,29 @@ __global__ __launch_bounds__(256) void chain_fwd_rows_kernel(const float* __rest
 // column permutations uses none.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// The coefficient rows, the low band and z are read ONCE by this kernel: non-temporal loads (no L2 allocation) move the inverse
+// chain from 4.75 to 5.0 TB/s and the forward chain from 4.6 to 5.0 - 5.3 TB/s at 48 channels x 512 x 512 (tools/chain_time.py);
+// non-temporal STORES add another 4 % to the inverse chain (5.25 TB/s) and cost the forward chain 2 %: CH_NT = 2 stores
+// non-temporally in the inverse direction only.
+#ifndef CH_NT
+#define CH_NT 2          // 0: plain accesses, 1: non-temporal loads, 2: + non-temporal stores of the inverse chain's output
+#endif
+#ifndef CH_SCALAR
+#define CH_SCALAR 0      // (tuning) 1: the block's row index through readfirstlane where a wave holds one row (scalar table loads)
+#endif
+__device__ __forceinline__ f4 ld_stream(const float* p) {
+#if CH_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+#else
+    return *reinterpret_cast<const f4*>(p);
+#endif
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float* p, f4 v) {
+    if constexpr (NT && CH_NT > 1) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+    else *reinterpret_cast<f4*>(p) = v;
+}
+
 // s (clamped) and t of four columns from the raw float4 rows of a stage
 __device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4& sr, const f4& tr, f4& s, f4& t) {
 #pragma unroll
@@ -750,8 +773,16 @@ __device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4&
     }
 }
 
+#ifndef CH_WAVES
+#define CH_WAVES 0       // (tuning) minimum waves per SIMD asked of the register allocator (0: none)
+#endif
 template <bool INV>
-__global__ __launch_bounds__(256) void chain_rows4_kernel(const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
+#if CH_WAVES
+__global__ __launch_bounds__(256, CH_WAVES) void chain_rows4_kernel(
+#else
+__global__ __launch_bounds__(256) void chain_rows4_kernel(
+#endif
+const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
                                                           cwfa_chain ch, const int64_t* __restrict__ final_perm, int C, int H, int W,
                                                           int64_t bs0, int64_t bs1, int64_t bs2, double* __restrict__ logdet,
                                                           double* __restrict__ sumsq) {
@@ -760,7 +791,14 @@ __global__ __launch_bounds__(256) void chain_rows4_kernel(const float* __restric
     extern __shared__ float rows[];          // [2][row of the block][W]: exchange buffers of the travelling values (column gathers)
     __shared__ double red[16];
     const int tpr = W >> 2, RB = 256 / tpr;
+#if CH_SCALAR
+    // a wave holds ONE image row when a row takes a multiple of 64 threads: the row index (and every table entry read with it)
+    // is then wave-uniform and goes through the scalar unit
+    const int r = (tpr & 63) == 0 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / tpr) : (int)threadIdx.x / tpr;
+    const int w4 = ((int)threadIdx.x - r * tpr) * 4;
+#else
     const int r = threadIdx.x / tpr, w4 = (threadIdx.x - r * tpr) * 4;
+#endif
     const int b = blockIdx.z, c = blockIdx.y, hh = blockIdx.x * RB + r;
     const bool live = hh < H;
     const int h = live ? hh : H - 1;
@@ -788,17 +826,17 @@ __global__ __launch_bounds__(256) void chain_rows4_kernel(const float* __restric
         sr[k] = tr[k] = zero;
         if (k < n) {
             const int64_t off = ((int64_t)q[k].c * H + q[k].h) * W + w4;
-            if (ch.stage[k].s_raw) sr[k] = *reinterpret_cast<const f4*>(ch.stage[k].s_raw + b * ch.stage[k].s_bs + off);
-            if (ch.stage[k].t) tr[k] = *reinterpret_cast<const f4*>(ch.stage[k].t + b * ch.stage[k].t_bs + off);
+            if (ch.stage[k].s_raw) sr[k] = ld_stream(ch.stage[k].s_raw + b * ch.stage[k].s_bs + off);
+            if (ch.stage[k].t) tr[k] = ld_stream(ch.stage[k].t + b * ch.stage[k].t_bs + off);
         }
     }
     f4 v0 = zero, lo = zero, own0 = zero, own1 = zero;
     const int64_t so = ((int64_t)src.h) * W + w4, oo = (int64_t)h * W + w4;
     if constexpr (INV) {
-        if (a2) v0 = *reinterpret_cast<const f4*>(a2 + b * bs2 + (int64_t)src.c * HW + so);
-        lo = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)c * HW + oo);
+        if (a2) v0 = ld_stream(a2 + b * bs2 + (int64_t)src.c * HW + so);
+        lo = ld_stream(a0 + b * bs0 + (int64_t)c * HW + oo);
     } else {
-        const f4 e0 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * src.c) * HW + so);
+        const f4 e0 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * src.c) * HW + so);      // (x is read twice: cached)
         const f4 e1 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * src.c + 1) * HW + so);
         own0 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * c) * HW + oo);
         own1 = *reinterpret_cast<const f4*>(a0 + b * bs0 + (int64_t)(2 * c + 1) * HW + oo);
@@ -839,8 +877,8 @@ __global__ __launch_bounds__(256) void chain_rows4_kernel(const float* __restric
     double sq = 0.0;
     if (live) {
         if constexpr (INV) {
-            *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)(2 * c) * HW + oo) = (lo + v) * CWFA_INV_SQRT2_F;
-            *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)(2 * c + 1) * HW + oo) = (lo - v) * CWFA_INV_SQRT2_F;
+            st_stream<true>(a1 + b * bs1 + (int64_t)(2 * c) * HW + oo, (lo + v) * CWFA_INV_SQRT2_F);
+            st_stream<true>(a1 + b * bs1 + (int64_t)(2 * c + 1) * HW + oo, (lo - v) * CWFA_INV_SQRT2_F);
         } else {
             *reinterpret_cast<f4*>(a1 + b * bs1 + (int64_t)c * HW + oo) = (own0 + own1) * CWFA_INV_SQRT2_F;
             *reinterpret_cast<f4*>(a2 + b * bs2 + (int64_t)c * HW + oo) = v;

@@ -103,9 +103,25 @@ def _drop_mask(p, B, C, device):
     return _Drop(torch.rand(B, C, device=device), p).mask()
 
 
-def _drop(p, B, C, device):
-    """The same draw, left pending (inference path)."""
-    return _Drop(torch.rand(B, C, device=device), p) if p else None
+def _drop(p, B, C, device, pool=None):
+    """The same draw, left pending (inference path).  ``pool``: a _DrawPool to slice the uniforms from (one RNG launch per forward)."""
+    if not p:
+        return None
+    return _Drop(pool.take(B, C) if pool is not None else torch.rand(B, C, device=device), p)
+
+
+class _DrawPool:
+    """All uniform draws of one forward pass from ONE torch.rand launch (six dropout2d masks per UNet pass otherwise cost six
+    launches of a few hundred numbers each)."""
+
+    def __init__(self, n, device):
+        self.u = torch.rand(n, device=device) if n > 0 else None
+        self.pos = 0
+
+    def take(self, B, C):
+        out = self.u[self.pos:self.pos + B * C].view(B, C)
+        self.pos += B * C
+        return out
 
 
 def _drop_affine(C, drop):
@@ -255,6 +271,11 @@ class UNet(nn.Module):
             raise NotImplementedError("store_activations is a debugging aid of the reference, not on the hot path")
         B, dev = x.shape[0], x.device
         skips, aff = [], in_affine
+        n_draw = 0
+        if self.drop_out:
+            n_draw = B * (sum(d.block[0].out_channels for d in list(self.down_path)[:-1]) +
+                          sum(u.conv_block.block[0].out_channels for u in self.up_path))
+        pool = _DrawPool(n_draw, dev)
         for i, down in enumerate(self.down_path):
             x, aff = down.run(x, in_affine=aff)
             if i != len(self.down_path) - 1:
@@ -263,10 +284,10 @@ class UNet(nn.Module):
                 # the normalised full-resolution map is written once for the skip connection
                 x, full = ops.maxpool(x, x.shape[-1] // 2, x.shape[-1] // 2, sc, sh, want_full=True)
                 skips.append(full)
-                m = _drop(self.drop_out, B, x.shape[1], dev)
+                m = _drop(self.drop_out, B, x.shape[1], dev, pool)
                 aff = _drop_affine(x.shape[1], m) if m is not None else None
         for i, up in enumerate(self.up_path):
-            m = _drop(self.drop_out, B, up.conv_block.block[0].out_channels, dev)
+            m = _drop(self.drop_out, B, up.conv_block.block[0].out_channels, dev, pool)
             x, aff = up.run(x, skips[-i - 1], in_affine=aff, out_mask=m)
         kind, alpha = UNetConvBlock._act(self.last[1])
         sc, sh = aff if aff is not None else (None, None)

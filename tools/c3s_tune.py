@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "_variants")
 SRC = "conv3d_split.hip"
-VARIANTS = {"base": ["-DC3S_DC_ENV"]}
+VARIANTS = {"p2s": ["-DC3S_PIPE=2", "-DC3S_STAGGER=1"], "p2s_prio1": ["-DC3S_PIPE=2", "-DC3S_STAGGER=1", "-DC3S_PRIO=1"], "p2_prio1": ["-DC3S_PIPE=2", "-DC3S_PRIO=1"], "stamp_prio": ["-DC3S_PIPE=2", "-DC3S_STAGGER=1", "-DC3S_PRIO=1", "-DC3S_STAMP=1"]}
 
 
 def build():
@@ -58,6 +58,18 @@ def run_one(name):
         tot += res[f"D{D}"]
     res["total_ms"] = round(tot, 4)
     print(json.dumps({"variant": name, "ms": res}), flush=True)
+    if name.startswith("stamp"):
+        import ctypes
+        x = torch.randn(1, 48, 512, 512, device="cuda")
+        ops.conv3d_1k1(x, w1, b1, a, w2, b2)
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 128)()
+        _lib.lib().cwfa_dbg_c3s_stamps(buf)
+        v = list(buf)
+        for wv in range(2):
+            for st in range(4):
+                row = v[(wv * 4 + st) * 16:(wv * 4 + st) * 16 + 11]
+                print("wave", wv * 4, "step", 10 + st, [row[i] - row[0] for i in range(11)], "abs0", row[0] - v[0], flush=True)
 
 
 if __name__ == "__main__":
