@@ -57,9 +57,9 @@ struct XG {
     static_assert(KS == 3 || RPW == 4, "7x7: 8-row tiles");
 };
 
-template <int MPW, int KS = 3, int RPW = 4>
+template <int MPW, int KS = 3, int RPW = 4, int WM = 4>
 struct Geo {
-    static constexpr int CT = 64 * MPW;                 // output channels per block
+    static constexpr int CT = 16 * MPW * WM;            // output channels per block (WM channel groups of 16 MPW)
     static constexpr int WSL = 3 * 4 * CT * 16;         // bytes of one weight slice (K = 32)
     static constexpr int LDS = 2 * XG<KS, RPW>::XB + 2 * WSL;   // 3x3, MPW = 4: 163 584 ... see the static_assert
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -129,18 +129,23 @@ __device__ __forceinline__ float soft_clamp(float a, int kind, float clamp) {
 
 // ADD: a second tensor is added on load (UNet skip); ACT1: compile-time activation of the common epilogues (bias -> ACT1),
 // EPI_RUNTIME = whatever cwfa_conv_opts says (bias -> act -> + residual -> act2)
-template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4>
+// WM = channel groups per block (4: the form described above; 2 / 1: the narrow tilings for banks with <= 32 / <= 16 outputs -- the
+// condition nets' 2-D convolutions and the output convolutions of the coarse steps' sub-networks, networks.py:212-219,633-638 --
+// on the 16-row tile: the eight waves are WM channel groups x 8 / WM row groups of 16 WM / 8 rows each)
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4, int WM = 4>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     typedef XG<KS, RPW> G;
-    constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD, NT = G::NT;
+    constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD;
+    constexpr int WN = 8 / WM, RW = G::TRW / WN, NT = 2 * RW;      // row groups, image rows and n-tiles per wave
     constexpr bool SPECIAL = G::SPECIAL;
     static_assert(SPECIAL || (MPW == 1 && !ADD), "7x7 / 16-row tiles: the 64-channel tiling without a skip add");
-    constexpr int CT = 64 * MPW;                        // output channels per block
+    static_assert(WM == 4 || (KS == 3 && RPW == 8 && MPW == 1 && ACT1 != EPI_COUPLE), "narrow tilings: 16-row tile, one m-tile per wave");
+    constexpr int CT = 16 * MPW * WM;                   // output channels per block
     constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it stays in SGPRs
-    const int wm = wave & 3, wn = wave >> 2;                            // channel group / row half of this wave
+    const int wm = wave % WM, wn = wave / WM;                           // channel group / row group of this wave
     const int HW = p.H * p.W;
     const int plane = HW * 4;
     constexpr unsigned OOB = 0x80000000u;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     };
 
     const int alane = OFF_W + (g * CT + wm * MPW * 16 + c16) * 16;        // + slot*WSL + (q*4*CT + mt*16)*16
-    const int blane = (g & 1) * KHB + (wn * RPW * XC + c16) * 16;            // + tap_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
+    const int blane = (g & 1) * KHB + (wn * RW * XC + c16) * 16;             // + tap_off + q*XPB + ((nt>>1)*XC + 16*(nt&1))*16
     const bool sel = (g >> 1) != 0;
 
     f32x4 acc[MPW][NT];
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
         float ssum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int row = row0 + wn * RPW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const int row = row0 + wn * RW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
             const bool ok = row < p.H && col < p.W;
             const unsigned po = ok ? (unsigned)((row * p.W + col) * 4) + jlane : OOB;
             float xv[NP];
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     // lane sums over its n-tiles, 16-lane DPP sums (pixels of a row), the block's two row halves through LDS (the operand
     // buffers are dead), then one float64 atomic pair per channel and block
     const bool want_stats = ACT1 != EPI_RUNTIME && p.o.out_stats != nullptr;
-    float* red = reinterpret_cast<float*>(lds);        // [wn 2][CT][2]
+    float* red = reinterpret_cast<float*>(lds);        // [wn WN][CT][2]
 #pragma unroll
     for (int mt = 0; mt < MPW; ++mt) {
         float bias[4];
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
             bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int row = row0 + wn * RPW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const int row = row0 + wn * RW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
             if constexpr (ACT1 != EPI_RUNTIME) {
                 if (outb) {
                     f32x4 o4;
@@ -548,8 +553,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int ch = ct * CT + tid;
             if (tid < CT && ch < p.Cout) {
-                const double s1 = (double)red[tid * 2] + (double)red[(CT + tid) * 2];
-                const double s2 = (double)red[tid * 2 + 1] + (double)red[(CT + tid) * 2 + 1];
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < WN; ++k) {
+                    s1 += (double)red[(k * CT + tid) * 2];
+                    s2 += (double)red[(k * CT + tid) * 2 + 1];
+                }
                 atomicAdd(&p.o.out_stats[2 * ch], s1);
                 atomicAdd(&p.o.out_stats[2 * ch + 1], s2);
             }
@@ -590,13 +599,16 @@ __global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restr
 }
 
 inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 64 ? 2 : 1; }
+// channel groups per block: the narrow tilings (32 / 16 output channels per block) for small banks -- packing and launch must agree
+inline int wm_of(int Cout) { return Cout > 32 ? 4 : Cout > 16 ? 2 : 1; }
+inline int ct_of(int Cout) { return 16 * mpw_of(Cout) * wm_of(Cout); }
 inline int nsteps_of(int Cin, int ntap = 9) { return ntap * (((Cin + 15) / 16 + 1) / 2); }   // whole periods of two 16-channel chunks
 
-template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4>
+template <int MPW, bool SIX, bool ADD, int ACT1, int KS = 3, int RPW = 4, int WM = 4>
 int launch(const SParams& p, hipStream_t stream) {
-    typedef Geo<MPW, KS, RPW> G;
+    typedef Geo<MPW, KS, RPW, WM> G;
     constexpr int TRW = XG<KS, RPW>::TRW;
-    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS, RPW>;
+    auto kern = &conv3x3_split_kernel<MPW, SIX, ADD, ACT1, KS, RPW, WM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -695,7 +707,7 @@ extern "C" int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packe
 
 extern "C" int64_t cwfa_conv3x3_split_packed_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return -1;
-    const int ct = 64 * mpw_of(Cout);
+    const int ct = ct_of(Cout);
     return (int64_t)((Cout + ct - 1) / ct) * nsteps_of(Cin) * 3 * 4 * ct * 16;
 }
 
@@ -703,11 +715,13 @@ extern "C" int cwfa_conv3x3_split_pack_f32(const float* w, void* packed, int Cou
     CWFA_REQUIRE(w && packed, CWFA_E_INVAL, "cwfa_conv3x3_split_pack_f32: null pointer");
     CWFA_REQUIRE(Cout > 0 && Cin > 0, CWFA_E_SHAPE, "cwfa_conv3x3_split_pack_f32: bad shape");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_conv3x3_split_pack_f32: packed image must be 16-byte aligned");
-    const int mpw = mpw_of(Cout), ct = 64 * mpw, nchunks = (Cin + 15) / 16, nsteps = nsteps_of(Cin);
+    const int mpw = mpw_of(Cout), ct = ct_of(Cout), nchunks = (Cin + 15) / 16, nsteps = nsteps_of(Cin);
     const int64_t total = (int64_t)((Cout + ct - 1) / ct) * nsteps * 4 * ct;
     const dim3 grid((unsigned)((total + 255) / 256));
     uint4* out = reinterpret_cast<uint4*>(packed);
-    if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    if (ct == 32) hipLaunchKernelGGL(split3x3_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else if (ct == 16) hipLaunchKernelGGL(split3x3_pack_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     else if (mpw == 2) hipLaunchKernelGGL(split3x3_pack_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     else hipLaunchKernelGGL(split3x3_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     CWFA_LAUNCH_CHECK("cwfa_conv3x3_split_pack_f32");
@@ -750,6 +764,21 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     const bool six = g_cwfa_split_products != 1;
     if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
     if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
+    const int wm = wm_of(Cout);
+    if (wm != 4) {       // narrow tilings (<= 32 outputs): 16-row tile, no load-side prologue, NCHW / blocked input, bias / PReLU / generic epilogue
+        CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add && !p.o.out_blocked8, CWFA_E_INVAL,
+                     "cwfa_conv3x3_split_f32: banks with <= 32 outputs take no load-side prologue and write NCHW");
+        const bool plain = !p.o.residual && p.o.act2 == CWFA_ACT_NONE;
+        const int epi = plain && p.o.act == CWFA_ACT_NONE ? 0 : plain && p.o.act == CWFA_ACT_PRELU ? 1 : 2;
+        if (wm == 2) {
+            if (epi == 0) return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8, 2>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8, 2>(p, st);
+            if (epi == 1) return six ? launch<1, true, false, CWFA_ACT_PRELU, 3, 8, 2>(p, st) : launch<1, false, false, CWFA_ACT_PRELU, 3, 8, 2>(p, st);
+            return six ? launch<1, true, false, EPI_RUNTIME, 3, 8, 2>(p, st) : launch<1, false, false, EPI_RUNTIME, 3, 8, 2>(p, st);
+        }
+        if (epi == 0) return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8, 1>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8, 1>(p, st);
+        if (epi == 1) return six ? launch<1, true, false, CWFA_ACT_PRELU, 3, 8, 1>(p, st) : launch<1, false, false, CWFA_ACT_PRELU, 3, 8, 1>(p, st);
+        return six ? launch<1, true, false, EPI_RUNTIME, 3, 8, 1>(p, st) : launch<1, false, false, EPI_RUNTIME, 3, 8, 1>(p, st);
+    }
     // 64-channel tiling: 16-row tiles for the plain bias-only form (the output convolutions of the sub-networks)
     if (g_cwfa_split_rows16 && H > 8 && !p.o.in_scale && !p.o.in_add && !p.o.residual && p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE)
         return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8>(p, st);

@@ -392,7 +392,7 @@ def pack_conv_weight(w, transposed=False):
         packed = torch.empty(L.cwfa_conv_split_packed_bytes(cout, cin, ks), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv_split_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
-    if _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT:
+    if _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT and (cout > 32 or (cout <= SPLIT_3X3_NARROW_MAX and cin >= 29)):
         packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv3x3_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv3x3_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
@@ -521,6 +521,21 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         check(L.cwfa_conv7x7_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o), _stream()),
               "conv7x7_split")
     elif pc.split and pc.ks == 3:
+        if pc.cout <= 32 and (in_scale is not None or in_add is not None):
+            # the narrow tilings take no load-side prologue: one streaming pass materialises it (no such layer in CWFA's graphs)
+            if (H * W) % 4 == 0:
+                x = plane_affine(x, in_scale, in_shift, add=in_add)
+            else:                               # odd plane sizes: per-channel affine pass(es) + an add pass
+                if in_scale is not None:
+                    if in_scale.numel() == Cin:
+                        x = channel_affine(x, in_scale.reshape(-1), in_shift.reshape(-1))
+                    else:
+                        x = torch.cat([channel_affine(x[i:i + 1], in_scale.reshape(B, Cin)[i].contiguous(), in_shift.reshape(B, Cin)[i].contiguous())
+                                       for i in range(B)], 0)
+                if in_add is not None:
+                    x = axpby(x.contiguous(), 1.0, in_add, 1.0)
+            x, xbs = planes(x, "x")
+            o.in_scale = o.in_shift = o.in_add = None
         # fp32-accurate conv on the bf16 pipe, the kernel splits x on the way into LDS (prologue included)
         check(L.cwfa_conv3x3_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o),
                                        _stream()), "conv3x3_split")
@@ -613,7 +628,12 @@ def couple_fused():
     return COUPLE_EPILOGUE and _split_bf16 >= 2
 
 
-SPLIT_3X3_MIN_COUT = 33     # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2
+SPLIT_3X3_MIN_COUT = 1      # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2 (banks with <= 32 /
+#                             <= 16 outputs: its narrow tilings of 32 / 16 channels per block; 33 = round 2's rule, those banks on fp32 Winograd)
+SPLIT_3X3_NARROW_MAX = 16   # banks with <= this many outputs (and >= 29 inputs) take the 16-channel tiling of the split-bf16 kernel; 17..32
+#                             outputs stay on the fp32 Winograd kernel.  Measured @512^2 (tools/small_conv_time.py, fp32 Winograd vs split): 64 -> 24:
+#                             71 vs 76 us, 64 -> 12: 66 vs 58, 64 -> 6: 62 vs 56, 29 -> 12: 38 vs 32, 29 -> 6: 35 vs 31, 24 -> 24: 34 vs 39, 6 -> 6: 15 vs 29
+#                             -- with so few MFMAs per step the per-step costs of the kernel (barrier, weight DMA, operand reads) decide
 conv_event_sink = None      # object with want(key)->bool and add(key, start_event, end_event); set by bench.py only
 
 

@@ -1239,7 +1239,9 @@ def test_split_bf16_conv_transpose():
 
 
 @pytest.mark.parametrize("cfg", [(1, 70, 7, 63, 200), (1, 256, 8, 64, 256), (2, 20, 12, 37, 320), (1, 6, 19, 40, 256),
-                                 (1, 48, 9, 33, 130), (2, 33, 17, 50, 520), (1, 64, 16, 32, 96), (1, 64, 5, 20, 12)])
+                                 (1, 48, 9, 33, 130), (2, 33, 17, 50, 520), (1, 64, 16, 32, 96), (1, 64, 5, 20, 12),
+                                 # the narrow tilings: 32 / 16 output channels per block on the 16-row tile (<= 32 / <= 16 outputs)
+                                 (1, 64, 33, 50, 24), (2, 29, 20, 40, 6), (1, 24, 16, 32, 32), (1, 64, 40, 64, 17), (1, 29, 9, 12, 16)])
 def test_split_bf16_3x3_is_fp32_accurate(cfg):
     """The split-bf16 3x3 kernel (K = 32 tap pairs on v_mfma_f32_16x16x32_bf16; tilings of 256 / 128 / 64 output channels):
     zero padding and the channel tail through the buffer range check, odd and even chunk counts, the load-side prologue
@@ -1260,10 +1262,17 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
     xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double()
     lin_pro = F.conv2d(xin, w.double(), b.double(), padding=1)
     ops.set_option("split_bf16", level)
-    keep_min = ops.SPLIT_3X3_MIN_COUT
-    ops.SPLIT_3X3_MIN_COUT = 1                 # also the narrow tilings
+    keep_min, keep_nar = ops.SPLIT_3X3_MIN_COUT, ops.SPLIT_3X3_NARROW_MAX
+    ops.SPLIT_3X3_MIN_COUT = 1                 # also the narrow tilings ...
+    ops.SPLIT_3X3_NARROW_MAX = 32              # ... for every bank with <= 32 outputs
     try:
-        pc = ops.pack_conv_weight(w.cuda())
+        pc = ops.pack_conv_weight(w.cuda()) if Cin >= 29 or Cout > 32 else None
+        if pc is None:                         # (the selection rule wants >= 29 inputs for the narrow tilings: pack directly)
+            L_ = ops._lib.lib()
+            packed = torch.empty(L_.cwfa_conv3x3_split_packed_bytes(Cout, Cin), dtype=torch.uint8, device="cuda")
+            wc = w.cuda().contiguous()
+            ops.check(L_.cwfa_conv3x3_split_pack_f32(ops._p(wc), ops._p(packed), Cout, Cin, ops._stream()), "pack")
+            pc = ops.PackedConv(packed, Cout, Cin, 3, False, wc._version, wc.data_ptr(), split=True)
         assert pc.split
         got = {"plain": ops.conv2d(x.cuda(), pc, bias=b.cuda()),
                "prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda()),
@@ -1273,7 +1282,7 @@ def test_split_bf16_3x3_is_fp32_accurate(cfg):
                "aff_prelu": ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=alpha.cuda(), in_scale=sc.cuda(),
                                        in_shift=sh.cuda())}
     finally:
-        ops.SPLIT_3X3_MIN_COUT = keep_min
+        ops.SPLIT_3X3_MIN_COUT, ops.SPLIT_3X3_NARROW_MAX = keep_min, keep_nar
         ops.set_option("split_bf16", 0)
     lin_aff = F.conv2d(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), w.double(), b.double(), padding=1)
     want = {"plain": ref, "prelu": F.prelu(ref, alpha.double()), "generic": F.relu(F.gelu(ref) + res.double()),
