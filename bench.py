@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--no-split7x7", action="store_true", help="(ablation) the ConvNeXt 7x7 convolution on the fp32 MFMA kernel")
     ap.add_argument("--no-rows16", action="store_true", help="(ablation) 8-row tiles for the 64-channel tiling of the split 3x3 kernel")
     ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
+    ap.add_argument("--no-first-composed", action="store_true", help="(ablation) the first layer of every sub-network like the other two "
+                    "(K = 9 x 64) instead of its composed form")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -241,6 +243,8 @@ def main():
         global WINO2D_MIN
         WINO2D_MIN = a.wino2d
         ops.set_option("winograd_2d", a.wino2d)
+    if a.no_first_composed:
+        ops.FIRST_LAYER_COMPOSED = False
     if a.no_couple_epilogue:
         ops.COUPLE_EPILOGUE = False
     if a.no_virtual_cat:

@@ -441,7 +441,8 @@ class _CatStepPlan:
         ``None`` in its place."""
         g = self.graph
         cond_of = dict(zip(g.condition_nodes, c))
-        stages, pending = self._stages(cond_of, rev)
+        with ops.ones_channel_scope():              # the blocks' sub-networks share their condition (+ ones channel, built once)
+            stages, pending = self._stages(cond_of, rev)
         first = next(t for t in x_or_z if t is not None)
         acc = torch.zeros(first.shape[0], dtype=torch.float64, device=first.device) if jac else None
         if rev:

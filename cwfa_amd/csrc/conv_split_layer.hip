@@ -48,7 +48,7 @@ constexpr int KHB = 9984;                   // bytes of one k-half plane: 18 x 3
 constexpr int XPB = 2 * KHB;                // bytes of one piece plane
 constexpr int XB = 3 * XPB;                 // bytes of one input buffer (59 904)
 constexpr int WSL = 3 * 4 * 64 * 16;        // bytes of one weight slice (12 288)
-constexpr int NSL = 20;                     // 18 slices of the 3x3 bank + 2 of the 1x1 bank
+constexpr int NSL = 20;                     // 18 slices of the 3x3 bank + 2 of the 1x1 bank (NPER = 1: 9 + 2)
 constexpr int OFF_W = 2 * XB;
 constexpr int OFF_DUMP = OFF_W + 3 * WSL;   // 4 KB: where waves 4..7 send their second (out-of-range, zero) slice DMA
 constexpr int MAXP = 5;                     // problems (filter banks) per launch: what the rest of the 160 KB holds in biases
@@ -67,6 +67,9 @@ struct LParams {
     int64_t x_bs, y_bs;
     int in_blocked, out_blocked;      // layout of x / y: 0 = NCHW planes, 1 = [C/8][H][W][8] (see the header comment)
     int xcd_map;
+    const float* u;                   // NPER = 1 ("first layer" form): the 3x3 reads THIS tensor (NCHW, u_ch <= 32 channels) with weights composed
+    int64_t u_bs;                     // with the 1x1 in front of the layer; x is then only the residual
+    int u_ch;
     int nprob, spp;                   // grouped launch: sample b belongs to problem b / spp, which has its own packed image (wp + problem *
                                       // NSL * WSL) and biases (b3 / b1 + problem * 64); nprob = 1: one bank for the whole batch
 };
@@ -110,8 +113,15 @@ __host__ __device__ constexpr int unit_off(int u) {
     return (chunk & 1) * XB + ((tap / 3) * XC + tap % 3) * 16;
 }
 
-template <bool SIX, bool INB, bool OUTB>
+// NPER = number of 9-step periods of the 3x3 = pairs of 16-channel input chunks: 2 for the 64-channel layer; 1 for the FIRST layer of
+// a sub-network in its composed form: conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1) with W' = W3 o [W0 | b0] over the <= 31 channels of
+// the sub-network's input u and a constant-one channel (exact with zero padding: the padded ones carry no bias), K = 9 x 32 instead
+// of 9 x 64 -- half the conv steps; the residual x = conv1x1(u) + b0 is still read from memory.
+template <bool SIX, bool INB, bool OUTB, int NPER = 2>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
+    constexpr int NSTEP = 9 * NPER, NSLK = NSTEP + 2;     // conv steps per tile; weight slices per problem
+    constexpr bool UIN = NPER == 1;                      // the 3x3 input is p.u (NCHW), not p.x
+    constexpr bool INS = INB && !UIN;                    // layout of the STAGED tensor
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
     const int HW = p.H * p.W;
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             const int gr = row0 + ((epk[k] >> 8) & 255) - 1, gc = col0 + (epk[k] & 255) - 1, eh = epk[k] >> 16;
             const bool ok = valid && fin[k] && gr >= 0 && gr < p.H && gc >= 0 && gc < p.W;
             // NCHW: channel 8 eh of the chunk, pixel (gr, gc); blocked: 32-byte entry (gr, gc) of channel block eh of the chunk
-            fo[k] = !ok ? OOB : INB ? (unsigned)((eh * HW + gr * p.W + gc) * 32) : (unsigned)((eh * 8 * HW + gr * p.W + gc) * 4);
+            fo[k] = !ok ? OOB : INS ? (unsigned)((eh * HW + gr * p.W + gc) * 32) : (unsigned)((eh * 8 * HW + gr * p.W + gc) * 4);
         }
     };
     auto rsrc_of = [&](const float* base) {
@@ -159,8 +169,9 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         col0 = (rem - ty * p.tiles_x) * TC;
     };
     auto load_entry = [&](f32x4 (&xv)[2], const float* base, unsigned fo, int chunk) {
-        const auto rs = rsrc_of(base);
-        if constexpr (INB) {                          // chunk = channel blocks 2 chunk, 2 chunk + 1: 16 planes further
+        // (the staged tensor: 64 channels of x, or the u_ch channels of u -- channels past the end read 0.0)
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (UIN ? p.u_ch : 64) * plane, 0x00020000);
+        if constexpr (INS) {                          // chunk = channel blocks 2 chunk, 2 chunk + 1: 16 planes further
             xv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, fo, chunk * 16 * plane, 0));
             xv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, fo, chunk * 16 * plane + 16, 0));   // (+16 in the SCALAR offset)
             return;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     };
 
     // ---- weight slices: 12 x 1 KB; every wave issues two DMA instructions (waves 4..7: the second into the dump area)
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, p.nprob * NSL * WSL, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, p.nprob * NSLK * WSL, 0x00020000);
     // `wb`: byte offset of the problem's packed image (scalar)
     auto dma_w = [&](int slice, int slot, int wb) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + OFF_W + slot * WSL + wave * 1024), 16, (unsigned)tid * 16u,
@@ -237,11 +248,11 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     int tile = blockIdx.x;
     int tb, row0, col0;
     tile_coords(tile, tb, row0, col0);
-    const float* xs_cur = p.x + (int64_t)tb * p.x_bs;
+    const float* xs_cur = UIN ? p.u + (int64_t)tb * p.u_bs : p.x + (int64_t)tb * p.x_bs;
     entry_offsets(true, row0, col0, fo_c);
     sfor<3>([&](auto kc) { load_entry(xa[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 0); });
     sfor<3>([&](auto kc) { load_entry(xb[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 1); });
-    int wb_cur = problem_of(tb) * (NSL * WSL);
+    int wb_cur = problem_of(tb) * (NSLK * WSL);
     dma_w(0, 0, wb_cur);
     sfor<3>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], 0); });
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -259,11 +270,11 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         const bool has_next = ntile < p.ntiles;
         int nb, nrow0, ncol0;
         tile_coords(has_next ? ntile : tile, nb, nrow0, ncol0);
-        const float* xs_next = p.x + (int64_t)nb * p.x_bs;
+        const float* xs_next = UIN ? p.u + (int64_t)nb * p.u_bs : p.x + (int64_t)nb * p.x_bs;
         entry_offsets(has_next, nrow0, ncol0, fo_n);
 
-        const int wb_next = problem_of(nb) * (NSL * WSL);
-        const f32x4* bias4 = bias_all + (wb_cur / (NSL * WSL)) * 32;
+        const int wb_next = problem_of(nb) * (NSLK * WSL);
+        const f32x4* bias4 = bias_all + (wb_cur / (NSLK * WSL)) * 32;
         // accumulators start from the conv bias (channel mt*16 + 4g + r)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -273,8 +284,9 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         }
 
         // ------------------------------------------------------------------------------------------ 18 conv steps
-        sfor<18>([&](auto sc) {
+        sfor<NSTEP>([&](auto sc) {
             constexpr int S = decltype(sc)::value, P = S % 9, PER = S / 9;
+            constexpr bool LASTP = PER == NPER - 1;            // the last period stages the NEXT tile's chunks 0 and 1
             const int s1 = next_slot(cs), s2 = next_slot(s1);
             constexpr bool LOADS = (P >= 2 && P <= 4) || P >= 6;
             // the slice DMA(s), then this step's staging loads (which may stay in flight across the barrier) -- issued from
@@ -283,33 +295,33 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             auto issue_memory = [&]() {
                 if constexpr (S == 0) dma_w(1, s1, wb_cur);     // (late by one step: the 1x1 phase counts as one)
                 dma_w(S + 2, s2, wb_cur);
-                if constexpr (P >= 2 && P <= 4) {               // even chunk 2*PER+2 (PER = 1: chunk 0 of the next tile)
+                if constexpr (P >= 2 && P <= 4) {               // even chunk 2*PER+2 (last period: chunk 0 of the next tile)
                     constexpr int k = P - 2;
-                    if constexpr (PER == 0) load_entry(xa[k], xs_cur, fo_c[k], 2);
+                    if constexpr (!LASTP) load_entry(xa[k], xs_cur, fo_c[k], 2 * PER + 2);
                     else load_entry(xa[k], xs_next, fo_n[k], 0);
                 }
-                if constexpr (P >= 6) {                         // odd chunk 2*PER+3 (PER = 1: chunk 1 of the next tile)
+                if constexpr (P >= 6) {                         // odd chunk 2*PER+3 (last period: chunk 1 of the next tile)
                     constexpr int k = P - 6;
-                    if constexpr (PER == 0) load_entry(xb[k], xs_cur, fo_c[k], 3);
+                    if constexpr (!LASTP) load_entry(xb[k], xs_cur, fo_c[k], 2 * PER + 3);
                     else load_entry(xb[k], xs_next, fo_n[k], 1);
                 }
             };
             const int ab = alane + cs * WSL;
             if constexpr (S == 1) read_a(0, ab, 0);             // slice 1 became visible with the barrier of step 0
-            constexpr int NS = (S + 1) % 18;                    // next step's B base (step 17: unused, the 1x1 phase follows)
+            constexpr int NS = (S + 1) % NSTEP;                 // next step's B base (last step: unused, the 1x1 phase follows)
             const int bbn = bbase_of(unit_off(2 * NS), unit_off(2 * NS + 1));
             FENCE();
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 if (mt < 3) read_a((mt + 1) & 1, ab, mt + 1);
-                else if (S != 0 && S != 17) read_a(0, alane + s1 * WSL, 0);    // first fragments of the next step
+                else if (S != 0 && S != NSTEP - 1) read_a(0, alane + s1 * WSL, 0);    // first fragments of the next step
                 FENCE();
 #pragma unroll
                 for (int np = 0; np < 4; np += 2) {
                     mfma6(acc[mt][np], A[mt & 1], Bq[np]);
                     mfma6(acc[mt][np + 1], A[mt & 1], Bq[np + 1]);
                     FENCE();
-                    if (mt == 3 && S != 17) {
+                    if (mt == 3 && S != NSTEP - 1) {
                         read_b(np, bbn);
                         read_b(np + 1, bbn);
                         FENCE();
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             if constexpr (LOADS && !INB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (LOADS) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (S != 17 && SIX) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            if constexpr (S != NSTEP - 1 && SIX) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cs = s1;
@@ -465,20 +477,21 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
 //                 element j = w3[co][chunk*16 + (g&1)*8 + j][tap]
 //   slices 18, 19 (k step s of the 1x1): element j of group g = w1[co][16*(2s + (j>>2)) + 4g + (j&3)] -- the hidden
 //                 channel that register j & 3 of accumulator tile 2s + (j >> 2) holds in lane group g
+// (n3 = 18 slices over cin3 = 64 input channels, or the first-layer form: n3 = 9 over cin3 = 32)
 __global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w1,
-                                                               uint4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice 20][g 4][co 64]
-    if (i >= NSL * 256) return;
+                                                               uint4* __restrict__ out, int n3, int cin3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice n3 + 2][g 4][co 64]
+    if (i >= (n3 + 2) * 256) return;
     const int co = i % 64, g = (i / 64) % 4, sl = i / 256;
     unsigned short pc[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v;
-        if (sl < 18) {
+        if (sl < n3) {
             const int u = 2 * sl + (g >> 1), c = u / 9, t = u % 9;
-            v = w3[((int64_t)co * 64 + c * 16 + (g & 1) * 8 + j) * 9 + t];
+            v = w3[((int64_t)co * cin3 + c * 16 + (g & 1) * 8 + j) * 9 + t];
         } else {
-            const int s = sl - 18;
+            const int s = sl - n3;
             v = w1[co * 64 + 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)];
         }
         __bf16 a1, a2, a3;
@@ -508,21 +521,40 @@ extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1
     CWFA_REQUIRE(w3 && w1 && packed, CWFA_E_INVAL, "cwfa_subnet_layer_split_pack_f32: null pointer");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_split_pack_f32: packed image must be 16-byte aligned");
     hipLaunchKernelGGL(split_layer_pack_kernel, dim3((NSL * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w1,
-                       reinterpret_cast<uint4*>(packed));
+                       reinterpret_cast<uint4*>(packed), 18, 64);
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_split_pack_f32");
     return CWFA_OK;
 }
 
+extern "C" int64_t cwfa_subnet_layer_first_packed_bytes(void) { return (int64_t)11 * WSL; }
+
+extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, void* packed, void* stream) {
+    CWFA_REQUIRE(w3c && w1 && packed, CWFA_E_INVAL, "cwfa_subnet_layer_first_pack_f32: null pointer");
+    CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_first_pack_f32: packed image must be 16-byte aligned");
+    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((11 * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3c, w1,
+                       reinterpret_cast<uint4*>(packed), 9, 32);
+    CWFA_LAUNCH_CHECK("cwfa_subnet_layer_first_pack_f32");
+    return CWFA_OK;
+}
+
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
-                        int64_t y_bs, int layout, int nprob, int spp, void* stream);
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u = nullptr, int64_t u_bs = 0, int u_ch = 0);
 
 extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                            int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream) {
     return layer_launch(x, packed, b3, b1, y, B, H, W, x_bs, y_bs, layout, 1, B > 0 ? B : 1, stream);
 }
 
+extern "C" int cwfa_subnet_layer_first_f32(const float* u, const float* x, const void* packed, const float* b3, const float* b1, float* y,
+                                           int B, int u_ch, int H, int W, int64_t u_bs, int64_t x_bs, int64_t y_bs, int layout, void* stream) {
+    CWFA_REQUIRE(u, CWFA_E_INVAL, "cwfa_subnet_layer_first_f32: null pointer");
+    CWFA_REQUIRE(u_ch >= 1 && u_ch <= 32, CWFA_E_SHAPE, "cwfa_subnet_layer_first_f32: 1 <= u_ch <= 32 (got %d)", u_ch);
+    CWFA_REQUIRE((int64_t)32 * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "cwfa_subnet_layer_first_f32: image too large for 32-bit offsets");
+    return layer_launch(x, packed, b3, b1, y, B, H, W, x_bs, y_bs, layout, 1, B > 0 ? B : 1, stream, u, u_bs, u_ch);
+}
+
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
-                        int64_t y_bs, int layout, int nprob, int spp, void* stream) {
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u, int64_t u_bs, int u_ch) {
     CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);
     CWFA_REQUIRE(!(layout & 1) || cwfa_aligned16(x), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input must be 16-byte aligned");
     CWFA_REQUIRE(!(layout & 2) || cwfa_aligned16(y), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output must be 16-byte aligned");
@@ -541,6 +573,7 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     p.out_blocked = (layout >> 1) & 1;
     p.nprob = nprob;
     p.spp = spp;
+    p.u = u; p.u_bs = u_bs; p.u_ch = u_ch;
     p.xcd_map = g_cwfa_split_xcd_map;
     p.tiles_x = (W + TC - 1) / TC;
     p.tiles_y = (H + TR - 1) / TR;
@@ -557,14 +590,19 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     }
     const bool six = g_cwfa_split_products != 1;
     typedef void (*kern_t)(LParams);
-    static const kern_t kerns[2][4] = {
-        {&split_layer_kernel<false, false, false>, &split_layer_kernel<false, true, false>, &split_layer_kernel<false, false, true>,
-         &split_layer_kernel<false, true, true>},
-        {&split_layer_kernel<true, false, false>, &split_layer_kernel<true, true, false>, &split_layer_kernel<true, false, true>,
-         &split_layer_kernel<true, true, true>}};
-    kern_t kern = kerns[six][layout];
-    static bool attr_set_all[2][4] = {};
-    bool& attr_done = attr_set_all[six][layout];
+    static const kern_t kerns[2][2][4] = {
+        {{&split_layer_kernel<false, false, false>, &split_layer_kernel<false, true, false>, &split_layer_kernel<false, false, true>,
+          &split_layer_kernel<false, true, true>},
+         {&split_layer_kernel<true, false, false>, &split_layer_kernel<true, true, false>, &split_layer_kernel<true, false, true>,
+          &split_layer_kernel<true, true, true>}},
+        {{&split_layer_kernel<false, false, false, 1>, &split_layer_kernel<false, true, false, 1>, &split_layer_kernel<false, false, true, 1>,
+          &split_layer_kernel<false, true, true, 1>},
+         {&split_layer_kernel<true, false, false, 1>, &split_layer_kernel<true, true, false, 1>, &split_layer_kernel<true, false, true, 1>,
+          &split_layer_kernel<true, true, true, 1>}}};
+    const int first = u != nullptr;
+    kern_t kern = kerns[first][six][layout];
+    static bool attr_set_all[2][2][4] = {};
+    bool& attr_done = attr_set_all[first][six][layout];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {

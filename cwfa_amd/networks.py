@@ -167,8 +167,18 @@ class wavelet_flow_subnetwork(nn.Module):
         # that layout -- the next layer, and the last convolution if it runs on the split-bf16 3x3 kernel
         pc_out = None if couple is not None else P(conv_out)
         last_reads_blocked = split_layers and ops.BLOCKED_MAPS and (couple is not None or (pc_out.split and pc_out.ks == 3))
+        # the first layer in its composed form (3x3 o 1x1 over the sub-network's few input channels + a ones channel: half the
+        # convolution steps) where the input is one tensor of <= 31 channels
+        first_form = (split_layers and ops.FIRST_LAYER_COMPOSED and not two and conv_in.kernel_size == (1, 1) and conv_in.in_channels <= 31
+                      and not pc_in.split)
         for i, blk in enumerate((self.block2, self.block4, self.block6)):
             if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
+                if split_layers and i == 0 and first_form:
+                    out_blocked = bool(ops.BLOCKED_MAPS)
+                    b = ops.subnet_layer_first(ops.with_ones(u), b, self._first3(conv_in, blk[0], blk[2]), blk[0].bias, blk[2].bias,
+                                               layout=int(blocked) | (int(out_blocked) << 1))
+                    blocked = out_blocked
+                    continue
                 if split_layers:                                        # both convs on the bf16 matrix pipe
                     out_blocked = ops.BLOCKED_MAPS and (i < 2 or last_reads_blocked)
                     b = ops.subnet_layer(b, self._split3(blk[0], blk[2]), blk[0].bias, None, blk[2].bias,
@@ -215,6 +225,14 @@ class wavelet_flow_subnetwork(nn.Module):
         u = parts[0] if len(parts) == 1 else list(parts)
         self._stack(u, self.block12, self.block72[1], couple=(x, out, clamp_kind, clamp, pre_scale, rev, logdet))
         return True
+
+    def _first3(self, conv0, conv3, conv1):
+        srcs = [conv0.weight, conv3.weight, conv1.weight] + ([conv0.bias] if conv0.bias is not None else [])
+        key = tuple((t._version, t.data_ptr()) for t in srcs) + (ops.pack_epoch(),)
+        hit = self._panels.get(("f", id(conv3)))
+        if hit is None or hit[0] != key:
+            hit = self._panels[("f", id(conv3))] = (key, ops.pack_first_layer_weight(conv0.weight, conv0.bias, conv3.weight, conv1.weight))
+        return hit[1]
 
     def _split3(self, conv3, conv1):
         w, w1 = conv3.weight, conv1.weight

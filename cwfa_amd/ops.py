@@ -662,6 +662,83 @@ def pack_split_layer_weight(w3, w1):
     return pc
 
 
+FIRST_LAYER_COMPOSED = True   # (tuning / ablation) False: the first layer of a sub-network runs like the other two (K = 9 x 64)
+
+
+def pack_first_layer_weight(w0, b0, w3, w1):
+    """The composed bank of a sub-network's FIRST layer (cwfa_subnet_layer_first_f32): conv3x3(conv1x1(u, w0) + b0, w3) =
+    conv3x3(u | 1, w3c) with w3c[o][i][tap] = sum_m w3[o][m][tap] [w0 | b0][m][i] (formed in float64, rounded once), zero-padded to
+    32 input channels; w0 [64,cin,1,1] with cin <= 31, b0 [64] or None, w3 [64,64,3,3], w1 [64,64,1,1]."""
+    L = _lib.lib()
+    w0, w3, w1 = _dev(w0, "w0").detach(), _dev(w3, "w3").detach(), _dev(w1, "w1").detach().contiguous()
+    cin = w0.shape[1]
+    if tuple(w0.shape) != (64, cin, 1, 1) or cin > 31 or tuple(w3.shape) != (64, 64, 3, 3) or tuple(w1.shape) != (64, 64, 1, 1):
+        raise ValueError("pack_first_layer_weight: 64-channel layers with a 1x1 bank of <= 31 inputs in front only")
+    w0p = torch.cat([w0.reshape(64, cin).double(), (b0.detach().double() if b0 is not None else torch.zeros(64, dtype=torch.float64, device=w0.device)).reshape(64, 1)], 1)
+    wc = torch.einsum("omt,mi->oit", w3.double().reshape(64, 64, 9), w0p)
+    w3c = torch.zeros((64, 32, 3, 3), dtype=torch.float32, device=w0.device)
+    w3c[:, :cin + 1] = wc.reshape(64, cin + 1, 3, 3).to(torch.float32)
+    packed = torch.empty(L.cwfa_subnet_layer_first_packed_bytes(), dtype=torch.uint8, device=w0.device)
+    check(L.cwfa_subnet_layer_first_pack_f32(_p(w3c), _p(w1), _p(packed), _stream()), "subnet_layer_first_pack")
+    pc = PackedConv(packed, 64, cin + 1, 3, False, w3._version, w3.data_ptr(), split=True)
+    pc.version1, pc.src_ptr1 = w1._version, w1.data_ptr()
+    return pc
+
+
+def subnet_layer_first(u1, x, pc, b3, b1, layout=0):
+    """y = ELU(conv1x1(ELU(conv3x3'(u1) + b3)) + b1 + x): the first layer of a sub-network with its 3x3 composed with the 1x1 in
+    front (pack_first_layer_weight).  ``u1``: the sub-network's input plus a constant-one channel [B, cin + 1 <= 32, H, W];
+    ``x`` = conv1x1(u) + b0, the residual ([B,64,H,W]; ``layout`` bits as in subnet_layer)."""
+    L = _lib.lib()
+    u1, ubs = planes(u1, "u1")
+    x, xbs = planes(x, "x")
+    B, Cu, H, W = u1.shape
+    if tuple(x.shape) != (B, 64, H, W) or Cu != pc.cin:
+        raise ValueError(f"subnet_layer_first: u1 {tuple(u1.shape)} / x {tuple(x.shape)} do not match the composed bank ({pc.cin} inputs)")
+    out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+    rec = conv_event_sink
+    if rec is not None:
+        key = ("L", 32, 64, H, W, B, "layer1+split", False)
+        if rec.want(key):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+    check(L.cwfa_subnet_layer_first_f32(_p(u1), _p(x), _p(pc.packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), B, Cu, H, W, ubs, xbs,
+                                        64 * H * W, int(layout), _stream()), "subnet_layer_first")
+    if rec is not None and rec.want(key):
+        e1.record()
+        rec.add(key, e0, e1)
+    return out
+
+
+_ones_scope = None
+
+
+class ones_channel_scope:
+    """Within this scope ``with_ones(t)`` is computed once per tensor OBJECT (the five sub-networks of a CAT step read the same
+    condition): cat(t, 1) through the strided plane-copy kernel."""
+
+    def __enter__(self):
+        global _ones_scope
+        self.prev, _ones_scope = _ones_scope, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _ones_scope
+        _ones_scope = self.prev
+        return False
+
+
+def with_ones(t):
+    hit = _ones_scope.get(id(t)) if _ones_scope is not None else None
+    if hit is not None and hit[0] is t:
+        return hit[1]
+    B, _, H, W = t.shape
+    u1 = concat_channels([t, torch.ones((B, 1, H, W), dtype=torch.float32, device=t.device)])
+    if _ones_scope is not None:
+        _ones_scope[id(t)] = (t, u1)
+    return u1
+
+
 def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False, layout=0):
     """y = ELU(conv1x1(ELU(conv3x3(x) + b3)) + b1 + x), 64 channels, one launch.  ``want_hidden`` (training forward):
     returns (y, h) with h = ELU(conv3x3(x) + b3), written by the same launch.  With ``pc3`` from

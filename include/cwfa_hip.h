@@ -358,6 +358,16 @@ int64_t cwfa_subnet_layer_split_packed_bytes(void);
 int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1, void* packed, void* stream);
 int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H,
                                 int W, int64_t x_bs, int64_t y_bs, int layout, void* stream);
+/* The FIRST layer of a sub-network in its composed form.  The 1x1 convolution in front of the three layers (networks.py:621-623,
+ * 641-643) and the layer's 3x3 are both linear with nothing in between, so conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1) with
+ * W' = W3 o [W0 | b0] over u's channels and a constant-one channel (exact under zero padding: padded ones carry no bias): K = 9 x 32
+ * instead of 9 x 64 -- half the convolution steps of the layer.  u: [B, u_ch <= 32, H, W] NCHW INCLUDING the ones channel;
+ * x = conv1x1(u) + b0 (the residual, layout bit 0); packed = cwfa_subnet_layer_first_pack_f32(w3c [64,32,3,3] the composed bank,
+ * zero in unused input channels; w1 [64,64,1,1]): cwfa_subnet_layer_first_packed_bytes() bytes. */
+int64_t cwfa_subnet_layer_first_packed_bytes(void);
+int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, void* packed, void* stream);
+int cwfa_subnet_layer_first_f32(const float* u, const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
+                                int u_ch, int H, int W, int64_t u_bs, int64_t x_bs, int64_t y_bs, int layout, void* stream);
 /* layout: bit 0 = x, bit 1 = y is CHANNEL-BLOCKED, [B][8 blocks][H][W][8 channels] (same size and batch strides as NCHW, 16-byte
  * aligned), instead of NCHW planes.  The maps between the layers of one sub-network are private to it; blocked, a staging entry
  * of the kernel (8 channels of a pixel) is two 16-byte loads instead of eight 4-byte ones and the four channels a lane holds for

@@ -1478,6 +1478,52 @@ def test_split_layer_channel_blocked_layouts(shape):
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("cfg", [(1, 6, 40, 70), (2, 12, 33, 50), (1, 24, 64, 64), (1, 31, 17, 33), (1, 1, 16, 32)])
+def test_first_layer_composed_form_is_fp32_accurate(cfg):
+    """cwfa_subnet_layer_first_f32: the first layer of a sub-network with its 3x3 composed with the 1x1 in front
+    (networks.py:621-631,641-665: conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1), K = 9 x 32) against float64 torch evaluating the two
+    convolutions one after the other -- borders (the ones channel is zero-padded like the map it stands for), ragged tiles, batch,
+    both residual layouts; then a whole sub-network with and without the form."""
+    from cwfa_amd import networks as N, ops
+    B, cin, H, W = cfg
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(cin + H)
+    u = torch.randn(B, cin, H, W, generator=g)
+    w0, b0 = torch.randn(64, cin, 1, 1, generator=g) / cin ** 0.5, torch.randn(64, generator=g) * 0.3
+    w3, b3 = torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g) * 0.1
+    w1, b1 = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1
+    x64 = F.conv2d(u.double(), w0.double(), b0.double())
+    ref = F.elu(F.conv2d(F.elu(F.conv2d(x64, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + x64)
+    ops.set_precision("split_bf16")
+    try:
+        pc = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda())
+        x = ops.conv2d(u.cuda(), ops.pack_conv_weight(w0.cuda()), bias=b0.cuda())
+        u1 = ops.with_ones(u.cuda())
+        assert u1.shape[1] == cin + 1 and float(u1[:, -1].min()) == 1.0
+        y = ops.subnet_layer_first(u1, x, pc, b3.cuda(), b1.cuda())
+        assert_close(y, ref, 5e-6, "composed first layer")
+        yb = ops.subnet_layer_first(u1, _to_blocked(x), pc, b3.cuda(), b1.cuda(), layout=3)
+        assert torch.equal(_from_blocked(yb), y)
+        # the plain layer on the same maps: the same function up to the rounding of x between the two convolutions
+        y2 = ops.subnet_layer(x, ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda())
+        assert_close(y2, y, 5e-6, "composed vs two-step")
+        with pytest.raises(ValueError):
+            ops.subnet_layer_first(u.cuda(), x, pc, b3.cuda(), b1.cuda())            # the ones channel is part of the contract
+        if cin == 12:
+            N.networks_n_chans = 64
+            torch.manual_seed(cin)
+            net = N.wavelet_flow_subnetwork2D(cin, 2 * cin).cuda()
+            with torch.no_grad():
+                a1 = net(u.cuda())
+                ops.FIRST_LAYER_COMPOSED = False
+                a0 = net(u.cuda())
+            assert not torch.equal(a0, a1)
+            assert_close(a1, a0, 5e-6, "sub-network with / without the composed first layer")
+    finally:
+        ops.FIRST_LAYER_COMPOSED = True
+        ops.set_precision("fp32")
+
+
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
