@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
     ap.add_argument("--no-first-composed", action="store_true", help="(ablation) the first layer of every sub-network like the other two "
                     "(K = 9 x 64) instead of its composed form")
+    ap.add_argument("--no-merge-first", action="store_true", help="(ablation) every sub-network runs its own first 1x1 convolution")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -245,6 +246,9 @@ def main():
         ops.set_option("winograd_2d", a.wino2d)
     if a.no_first_composed:
         ops.FIRST_LAYER_COMPOSED = False
+    if a.no_merge_first:
+        from cwfa_amd import networks as _N
+        _N.MERGE_FIRST_MAPS = False
     if a.no_couple_epilogue:
         ops.COUPLE_EPILOGUE = False
     if a.no_virtual_cat:

@@ -441,7 +441,10 @@ class _CatStepPlan:
         ``None`` in its place."""
         g = self.graph
         cond_of = dict(zip(g.condition_nodes, c))
-        with ops.ones_channel_scope():              # the blocks' sub-networks share their condition (+ ones channel, built once)
+        from ...networks import merged_first_maps
+        jobs = [(n.module.subnet, [cond_of[cn] for cn in n.conditions]) for k, n in self.chain if k == "cat"]
+        # the blocks' sub-networks share their condition: its ones channel is built once, their first 1x1 maps in one launch
+        with ops.ones_channel_scope(), ops.first_map_scope(merged_first_maps(jobs)):
             stages, pending = self._stages(cond_of, rev)
         first = next(t for t in x_or_z if t is not None)
         acc = torch.zeros(first.shape[0], dtype=torch.float64, device=first.device) if jac else None

@@ -703,7 +703,7 @@ int launch_sel(const ConvParams& p, int epi, hipStream_t st) {
         case EPI_UP: if constexpr (ALLOWED & (1u << EPI_UP)) return launch_epi<C, EPI_UP, PRO>(p, st); break;
         case EPI_NONE_BLK8:
             if constexpr (ALLOWED & (1u << EPI_NONE_BLK8)) return launch_epi<C, EPI_NONE_BLK8, PRO>(p, st);
-            cwfa_set_error("cwfa_conv2d_f32: out_blocked8 is built for the 1x1 kernels with 33..64 output channels");
+            cwfa_set_error("cwfa_conv2d_f32: out_blocked8 is built for the 1x1 kernels with more than 32 output channels");
             return CWFA_E_SHAPE;
         default: break;
     }
@@ -1120,7 +1120,7 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
         switch (s.id) {
             case 3: return launch<C1v_32, N | P | G, P>(p, epi, st);
             case 4: return launch<C1v_64, N | RE | G | K, 0>(p, epi, st);
-            default: return launch<C1v_128, N | U, U>(p, epi, st);
+            default: return launch<C1v_128, N | U | K, U>(p, epi, st);
         }
     }
     switch (s.id) {
@@ -1129,7 +1129,7 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
         case 2: return launch<C3_128, N | P, P>(p, epi, st);
         case 3: return launch<C1_32, N | P | G, P>(p, epi, st);
         case 4: return launch<C1_64, N | RE | G | K, 0>(p, epi, st);
-        case 5: return launch<C1_128, N | U, U>(p, epi, st);
+        case 5: return launch<C1_128, N | U | K, U>(p, epi, st);
         case 6: return launch<C7_32, N, 0>(p, epi, st);
         default: return launch<C7_64, N, 0>(p, epi, st);
     }

@@ -158,7 +158,10 @@ class wavelet_flow_subnetwork(nn.Module):
         pc_in = self._cat_bank(conv_in, u[0].shape[1]) if two else P(conv_in)
         # the first map is channel-blocked already when the 1x1 kernel that writes it can do so (see below)
         blocked = bool(split_layers and ops.BLOCKED_MAPS and not pc_in.split and pc_in.ks == 1 and pc_in.cout == 64)
-        if two:
+        pre = ops.first_map_of(self)             # computed by the plan together with the other sub-networks' (ops.first_map_scope)
+        if pre is not None and pre[0] is u and pre[1] is conv_in and blocked:
+            b = pre[2]
+        elif two:
             b = ops.conv2d(u[0], pc_in, bias=conv_in.bias, out_blocked=blocked, cat=u[1])
         else:
             b = ops.conv2d(u, pc_in, bias=conv_in.bias, out_blocked=blocked)
@@ -226,6 +229,24 @@ class wavelet_flow_subnetwork(nn.Module):
         self._stack(u, self.block12, self.block72[1], couple=(x, out, clamp_kind, clamp, pre_scale, rev, logdet))
         return True
 
+    def first_conv_of(self, parts):
+        """(input tensor, 1x1 module) of this sub-network's first convolution for the condition list ``parts`` if that is ONE tensor
+        read by a plain 1x1 with bias (what MergedFirstMaps can stack), else None."""
+        if self.conv_type is not nn.Conv2d or self.n_ch != 64:
+            return None
+        if self.normal:
+            if len(parts) != 1:
+                return None
+            u, conv = parts[0], self.block12
+        else:
+            n = self.c_in // 2
+            if not (len(parts) == 2 and parts[1].shape[1] == n):
+                return None
+            u, conv = parts[1], self.block1
+        if conv.kernel_size != (1, 1) or conv.bias is None or conv.in_channels != u.shape[1]:
+            return None
+        return u, conv
+
     def _first3(self, conv0, conv3, conv1):
         srcs = [conv0.weight, conv3.weight, conv1.weight] + ([conv0.bias] if conv0.bias is not None else [])
         key = tuple((t._version, t.data_ptr()) for t in srcs) + (ops.pack_epoch(),)
@@ -288,6 +309,41 @@ class wavelet_flow_subnetwork(nn.Module):
             C.c_void_p(zero.data_ptr()), 1, None, None, B, mean.shape[1], H * W, mbs, out.shape[1] * H * W,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "subnet_first tail")
         return out
+
+
+MERGE_FIRST_MAPS = True      # (tuning / ablation) False: every sub-network runs its own first 1x1 convolution
+
+_merged_banks = {}
+
+
+def merged_first_maps(jobs):
+    """``jobs``: [(sub-network, condition list)] of the blocks of a CAT step.  Where at least two sub-networks read the same tensor
+    through a plain 1x1 (they all do: the condition), their banks are stacked and ONE launch writes all first maps, each a
+    channel-blocked 64-channel chunk of one tensor.  Returns the dict for ops.first_map_scope (empty when the form does not apply:
+    precision other than split / bf16, 3-D sub-networks, ...)."""
+    if not (MERGE_FIRST_MAPS and ops._split_bf16 >= 2 and ops.BLOCKED_MAPS):
+        return {}
+    groups = {}
+    for net, parts in jobs:
+        fc = net.first_conv_of(parts) if hasattr(net, "first_conv_of") else None
+        if fc is not None:
+            groups.setdefault(id(fc[0]), []).append((net, fc[0], fc[1]))
+    out = {}
+    for members in groups.values():
+        u = members[0][1]
+        if len(members) < 2 or (64 * len(members) + 64) * u.shape[2] * u.shape[3] * 4 >= 2 ** 31:
+            continue
+        convs = [m[2] for m in members]
+        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in convs) + (ops.pack_epoch(),)
+        hit = _merged_banks.get(id(convs[0]))
+        if hit is None or hit[0] != key:
+            w = torch.cat([c.weight.detach() for c in convs], 0).contiguous()
+            # (the fp32 MFMA 1x1 kernel, as for the separate 64-output banks: the launch is bound by its 64 n output planes)
+            hit = _merged_banks[id(convs[0])] = (key, ops.pack_conv_weight(w, direct=True), torch.cat([c.bias.detach() for c in convs]).contiguous())
+        X = ops.conv2d(u, hit[1], bias=hit[2], out_blocked=True)
+        for k, (net, _, conv) in enumerate(members):
+            out[id(net)] = (u, conv, X[:, 64 * k:64 * (k + 1)])
+    return out
 
 
 class wavelet_flow_subnetwork2D(wavelet_flow_subnetwork):

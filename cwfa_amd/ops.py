@@ -375,8 +375,9 @@ class PackedConv:
         self.epoch = _pack_epoch    # set_option() generation this image was built under (caches re-pack on a change)
 
 
-def pack_conv_weight(w, transposed=False):
-    """w: [Cout,Cin,k,k] (k in 1,3,7), or with transposed=True a ConvTranspose2d weight [Cin,Co,2,2]."""
+def pack_conv_weight(w, transposed=False, direct=False):
+    """w: [Cout,Cin,k,k] (k in 1,3,7), or with transposed=True a ConvTranspose2d weight [Cin,Co,2,2].  ``direct``: the fp32 MFMA
+    kernels' layout whatever the precision mode (banks whose launch is bound by its output stores, not by the matrix pipe)."""
     L = _lib.lib()
     w = _dev(w, "weight").detach().contiguous()
     if transposed:
@@ -388,15 +389,17 @@ def pack_conv_weight(w, transposed=False):
         cout, cin, ks, kw = w.shape
         if ks != kw:
             raise ValueError("square kernels only")
-    if _split_bf16 and ks == 1 and cout >= 128:
+    if direct:
+        pass
+    elif _split_bf16 and ks == 1 and cout >= 128:
         packed = torch.empty(L.cwfa_conv_split_packed_bytes(cout, cin, ks), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv_split_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
-    if _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT and (cout > 32 or (cout <= SPLIT_3X3_NARROW_MAX and cin >= 29)):
+    if not direct and _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT and (cout > 32 or (cout <= SPLIT_3X3_NARROW_MAX and cin >= 29)):
         packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv3x3_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv3x3_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
-    if SPLIT_7X7 and _split_bf16 >= 2 and ks == 7 and cout <= 64 and cin >= 32:   # the ConvNeXt convolution of the LRNN (64 -> 64)
+    if not direct and SPLIT_7X7 and _split_bf16 >= 2 and ks == 7 and cout <= 64 and cin >= 32:   # the ConvNeXt convolution of the LRNN (64 -> 64)
         packed = torch.empty(L.cwfa_conv7x7_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv7x7_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv7x7_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
@@ -493,7 +496,7 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         o.in_blocked8 = 1
     if out_blocked:                         # y leaves channel-blocked: the split-bf16 3x3 kernel (bias / PReLU epilogue), or plain 1x1
         ok3 = pc.split and pc.ks == 3 and pc.cout % 8 == 0 and residual is None and act2 is None and act in (None, "prelu")
-        ok1 = not pc.split and pc.ks == 1 and 33 <= pc.cout <= 64 and pc.cout % 8 == 0 and not up
+        ok1 = not pc.split and pc.ks == 1 and pc.cout >= 33 and pc.cout % 8 == 0 and not up
         if not (ok3 or ok1):                # banks with 33..64 outputs on the fp32 MFMA kernel
             raise ValueError("conv2d: channel-blocked output is written by the split-bf16 3x3 kernel (bias / PReLU) and by the "
                              "direct 1x1 kernel with 40..64 output channels only")
@@ -711,6 +714,30 @@ def subnet_layer_first(u1, x, pc, b3, b1, layout=0):
 
 
 _ones_scope = None
+_first_maps = None          # {id(sub-network): its first map x = conv1x1(u) + b0, channel-blocked} while a plan has them merged
+
+
+class first_map_scope:
+    """The first 1x1 convolutions of several sub-networks that read the SAME tensor (the five blocks of a CAT step all read the
+    condition: coupling_layers.py:475-500, networks.py:621-623) as ONE launch with their banks stacked: the five 64-channel maps
+    leave as consecutive channel-blocked chunks of one [B, 64 n, H, W] tensor."""
+
+    def __init__(self, maps):
+        self.maps = maps
+
+    def __enter__(self):
+        global _first_maps
+        self.prev, _first_maps = _first_maps, self.maps
+        return self
+
+    def __exit__(self, *exc):
+        global _first_maps
+        _first_maps = self.prev
+        return False
+
+
+def first_map_of(net):
+    return None if _first_maps is None else _first_maps.get(id(net))
 
 
 class ones_channel_scope:

@@ -1524,6 +1524,40 @@ def test_first_layer_composed_form_is_fp32_accurate(cfg):
         ops.set_precision("fp32")
 
 
+def test_cat_step_with_merged_first_maps_equals_the_separate_launches():
+    """ops.first_map_scope / networks.merged_first_maps: the first 1x1 convolutions of the five sub-networks of a CAT step (they all
+    read the condition, coupling_layers.py:475-500) as ONE launch with stacked banks -- bit-identical to one launch per sub-network
+    (same kernel, same arithmetic per output channel), both directions, batch 2, a ragged size."""
+    from cwfa_amd import CWFA, networks as N, ops
+    torch.manual_seed(21)
+    np.random.seed(21)
+    conv_inn, _ = CWFA.build_networks(16, 40, 2, with_lrnn=False, cond_chans=4, device="cuda")    # 64 internal channels
+    gi = conv_inn[0]
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 16, 40, 40, generator=g).cuda()
+    c = [torch.randn(2, 8, 40, 40, generator=g).cuda(), 0.1 * torch.randn(2, 8, 40, 40, generator=g).cuda()]
+    low = torch.randn(2, 8, 40, 40, generator=g).cuda()
+    calls = []
+    real = N.merged_first_maps
+    ops.set_precision("split_bf16")
+    try:
+        outs = []
+        for flag in (True, False):
+            N.MERGE_FIRST_MAPS = flag
+            N.merged_first_maps = lambda jobs: (calls.append(len(real(jobs))), real(jobs))[1]
+            with torch.no_grad():
+                (z, lo), j = gi(x, c=c)
+                xi, _ = gi([None, low], c=c, rev=True)
+            outs.append((z, lo, j, xi))
+        assert calls == [5, 5, 0, 0], calls                    # all five sub-networks merged when on, none when off
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        N.merged_first_maps = real
+        N.MERGE_FIRST_MAPS = True
+        ops.set_precision("fp32")
+
+
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
