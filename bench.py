@@ -128,6 +128,8 @@ class ConvEvents:
 
 def conv_flops(key):
     ks, cin, cout, H, W, B = key[:6]
+    if ks == "L" and key[6].startswith("layer1"):   # first layer in composed form: 3x3 over the (padded) 32 input channels + the 64 x 64 1x1
+        return 2.0 * cout * (cin * 9 + cout) * H * W * B
     taps = 10 if ks == "L" else ks * ks          # "L": fused 3x3 + 1x1 sub-network layer (9 + 1 taps)
     return 2.0 * cout * cin * taps * H * W * B
 
@@ -136,6 +138,8 @@ def conv_bytes(key):
     """Algorithmic HBM bytes of one launch: every input tensor (x, and the skip tensor of a load-side add) read once, the
     output written once; the fused layer's residual is the x tile it already holds.  Weights are L2-resident noise."""
     ks, cin, cout, H, W, B = key[:6]
+    if ks == "L" and key[6].startswith("layer1"):   # u (+ ones channel) and the residual map x are read, y is written
+        return 4.0 * (cin + 2 * cout) * H * W * B
     return 4.0 * (cin * (2 if key[7] else 1) + cout) * H * W * B
 
 
