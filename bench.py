@@ -60,10 +60,17 @@ def family(key):
         if tag.endswith("couple+split"):
             act1 = -2
         mpw = 4 if cout > 128 else 2 if cout > 64 else 1
-        rpw = 8 if (ROWS16 and mpw == 1 and H > 8 and act1 in (0, -2)) else 4      # 16-row tiles: the plain 64-channel tiling
-        return "conv3x3_split_kernel<%d, %s, %s, %d, 3, %d>" % (mpw, "true" if SPLIT_SIX else "false", "true" if key[7] else "false", act1, rpw)
+        wm = 4 if cout > 32 else 2 if cout > 16 else 1                             # channel groups per block: narrow tilings for small banks
+        rpw = 4
+        if wm == 4 and mpw == 1 and ROWS16 and H > 8 and not pro and not key[7]:   # 64-channel tiling without a load-side prologue: 16-row tiles,
+            rpw, act1 = 8, (act1 if act1 in (0, -2) else -1)                        # bias-only / coupling epilogue compiled in, anything else at run time
+        if wm != 4:
+            rpw = 8
+        if wm != 4:
+            act1 = 0 if (plain and not act) else 2 if (plain and act == "prelu") else -1
+        return "conv3x3_split_kernel<%d, %s, %s, %d, 3, %d, %d>" % (mpw, "true" if SPLIT_SIX else "false", "true" if key[7] else "false", act1, rpw, wm)
     if tag.endswith("+split") and ks == 7:
-        return "conv3x3_split_kernel<1, %s, false, 0, 7, 4>" % ("true" if SPLIT_SIX else "false")
+        return "conv3x3_split_kernel<1, %s, false, 0, 7, 4, 4>" % ("true" if SPLIT_SIX else "false")
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:
@@ -76,9 +83,9 @@ def family(key):
 # kernel family (see family()) -> substrings of the rocprofv3 kernel names it covers (tools/pmc_traffic.py averages FETCH_SIZE /
 # WRITE_SIZE over the launches of all of them; the layer kernel has one instantiation per map layout)
 ROCPROF_NAMES = {
-    "conv3x3_split_kernel<4, true, false, 2, 3, 4>": ["conv3x3_split_kernel<4, true, false, 2, 3, 4>"],
-    "conv3x3_split_kernel<4, true, true, 2, 3, 4>": ["conv3x3_split_kernel<4, true, true, 2, 3, 4>"],
-    "conv3x3_split_kernel<4, false, false, 2, 3, 4>": ["conv3x3_split_kernel<4, false, false, 2, 3, 4>"],
+    "conv3x3_split_kernel<4, true, false, 2, 3, 4, 4>": ["conv3x3_split_kernel<4, true, false, 2, 3, 4, 4>"],
+    "conv3x3_split_kernel<4, true, true, 2, 3, 4, 4>": ["conv3x3_split_kernel<4, true, true, 2, 3, 4, 4>"],
+    "conv3x3_split_kernel<4, false, false, 2, 3, 4, 4>": ["conv3x3_split_kernel<4, false, false, 2, 3, 4, 4>"],
     "split_layer_kernel": ["split_layer_kernel<"],
     "wino_layer_kernel": ["wino_layer_kernel<false>"],
     "conv3x3_wino2d_kernel[|prelu|||]": ["conv3x3_wino2d_kernel<2, false, true>"],
@@ -387,11 +394,16 @@ def main():
                 try:                                          # never let a side measurement cost the headline line
                     ops.set_precision(PREC[mode])
                     dt = timed(step, max(a.steps // 2, 3))
+                    roof = None
+                    if mode == "bf16":                        # configs[4] carries its own roofline object: dominant kernel of THIS mode
+                        roof = mode_roofline(ops, step, "bf16")
                     res[name] = {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": max(a.steps // 2, 3),
                                  "note": {"fp32": "the same step on the plain fp32 MFMA kernels (Winograd F(2,3) / F(2x2,3x3)), after the timed region",
                                           "bf16": "BASELINE.json configs[4]: bf16 conv operands, fp32 accumulation; parity max-rel <= 1e-2, "
                                                   "L2-rel <= 5e-3 vs the fp32 oracle (tests/test_gpu_parity.py::test_full_config3_inverse_vs_oracle)",
                                           "split": "fp32-equivalent split-bf16 arithmetic (see --precision)"}[mode]}
+                    if roof is not None:
+                        res[name]["roofline"] = roof
                 except Exception as exc:                      # noqa: BLE001
                     res[name] = {"error": repr(exc)[:300]}
                 finally:
@@ -412,6 +424,32 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def mode_roofline(ops, step, mode):
+    """Roofline object of the dominant conv kernel of another precision mode (ops.set_precision already done): one selection
+    pass with events on every conv launch, then three passes with events on the dominant family only.  In bf16 mode the split
+    kernels run their one-product instantiations (SIX = false): issued = algorithmic FLOPs, peak = the bf16 dense peak."""
+    global SPLIT_SIX
+    import torch
+    six, SPLIT_SIX = SPLIT_SIX, mode != "bf16"
+    try:
+        sel = ops.conv_event_sink = ConvEvents()
+        step()
+        torch.cuda.synchronize()
+        tot = sel.totals()
+        all_ms = sum(t[0] for t in tot.values())
+        dom = max(tot, key=lambda k: tot[k][0])
+        sink = ops.conv_event_sink = ConvEvents(only={dom})
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ops.conv_event_sink = None
+        t, n, f, sh = sink.totals()[dom]
+        return roofline_of(dom, t, n, f, sh, 1 if mode == "bf16" else SPLIT_PRODUCTS, tot[dom][0] / all_ms, all_ms)
+    finally:
+        ops.conv_event_sink = None
+        SPLIT_SIX = six
 
 
 def forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_all, products, per_gpu=4, steps=5):

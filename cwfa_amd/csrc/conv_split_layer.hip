@@ -70,6 +70,8 @@ struct LParams {
     const float* u;                   // NPER = 1 ("first layer" form): the 3x3 reads THIS tensor (NCHW, u_ch <= 32 channels) with weights composed
     int64_t u_bs;                     // with the 1x1 in front of the layer; x is then only the residual
     int u_ch;
+    float* hid;                       // TAPE form (training forward): the hidden map h = ELU(conv3x3(x) + b3) is written here (NCHW), from the
+    int64_t hid_bs;                   // registers that hold it as the 1x1's B operand
     int nprob, spp;                   // grouped launch: sample b belongs to problem b / spp, which has its own packed image (wp + problem *
                                       // NSL * WSL) and biases (b3 / b1 + problem * 64); nprob = 1: one bank for the whole batch
 };
@@ -117,8 +119,9 @@ __host__ __device__ constexpr int unit_off(int u) {
 // a sub-network in its composed form: conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1) with W' = W3 o [W0 | b0] over the <= 31 channels of
 // the sub-network's input u and a constant-one channel (exact with zero padding: the padded ones carry no bias), K = 9 x 32 instead
 // of 9 x 64 -- half the conv steps; the residual x = conv1x1(u) + b0 is still read from memory.
-template <bool SIX, bool INB, bool OUTB, int NPER = 2>
+template <bool SIX, bool INB, bool OUTB, int NPER = 2, bool TAPE = false>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
+    static_assert(!TAPE || (!INB && !OUTB && NPER == 2), "tape form: NCHW maps, full layer");
     constexpr int NSTEP = 9 * NPER, NSLK = NSTEP + 2;     // conv steps per tile; weight slices per problem
     constexpr bool UIN = NPER == 1;                      // the 3x3 input is p.u (NCHW), not p.x
     constexpr bool INS = INB && !UIN;                    // layout of the STAGED tensor
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             dma_w(0, sn0, wb_next);
             const auto rx = rsrc_of(p.x + (int64_t)tb * p.x_bs);
             const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)tb * p.y_bs, 0, 64 * plane, 0x00020000);
+            const auto rh = __builtin_amdgcn_make_buffer_rsrc(TAPE ? p.hid + (int64_t)tb * p.hid_bs : p.y, 0, TAPE ? 64 * plane : 0, 0x00020000);
             // offsets of this lane's (row, col) in the two layouts: NCHW: channel 4 g (+ 16 mt + r planes in the scalar offset);
             // blocked: 16-byte half g & 1 of the 32-byte entry of channel block g >> 1 (+ 2 mt blocks = 16 mt planes)
             unsigned oo[4], ob[4];
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         __bf16 h1, h2 = (__bf16)0.f, h3 = (__bf16)0.f;
-                        split3<SIX>(elu(acc[2 * s + (j >> 2)][nt][j & 3]), h1, h2, h3);
+                        const float hv = elu(acc[2 * s + (j >> 2)][nt][j & 3]);
+                        if constexpr (TAPE)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), rh, oo[nt], ((2 * s + (j >> 2)) * 16 + (j & 3)) * plane, 0);
+                        split3<SIX>(hv, h1, h2, h3);
                         Hq[s][0][j] = h1; Hq[s][1][j] = h2; Hq[s][2][j] = h3;
                     }
                 read_a1(0);
@@ -538,7 +545,15 @@ extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w
 }
 
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
-                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u = nullptr, int64_t u_bs = 0, int u_ch = 0);
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u = nullptr, int64_t u_bs = 0, int u_ch = 0,
+                        float* hid = nullptr, int64_t hid_bs = 0);
+
+extern "C" int cwfa_subnet_layer_split_tape_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, float* hid, int B,
+                                                int H, int W, int64_t x_bs, int64_t y_bs, int64_t hid_bs, void* stream) {
+    CWFA_REQUIRE(hid || B == 0 || H == 0 || W == 0, CWFA_E_INVAL, "cwfa_subnet_layer_split_tape_f32: null pointer");
+    CWFA_REQUIRE(hid != x && hid != y, CWFA_E_INVAL, "cwfa_subnet_layer_split_tape_f32: the hidden map needs its own buffer");
+    return layer_launch(x, packed, b3, b1, y, B, H, W, x_bs, y_bs, 0, 1, B > 0 ? B : 1, stream, nullptr, 0, 0, hid, hid_bs);
+}
 
 extern "C" int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                            int H, int W, int64_t x_bs, int64_t y_bs, int layout, void* stream) {
@@ -554,7 +569,7 @@ extern "C" int cwfa_subnet_layer_first_f32(const float* u, const float* x, const
 }
 
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
-                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u, int64_t u_bs, int u_ch) {
+                        int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u, int64_t u_bs, int u_ch, float* hid, int64_t hid_bs) {
     CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);
     CWFA_REQUIRE(!(layout & 1) || cwfa_aligned16(x), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input must be 16-byte aligned");
     CWFA_REQUIRE(!(layout & 2) || cwfa_aligned16(y), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output must be 16-byte aligned");
@@ -574,6 +589,7 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     p.nprob = nprob;
     p.spp = spp;
     p.u = u; p.u_bs = u_bs; p.u_ch = u_ch;
+    p.hid = hid; p.hid_bs = hid_bs;
     p.xcd_map = g_cwfa_split_xcd_map;
     p.tiles_x = (W + TC - 1) / TC;
     p.tiles_y = (H + TR - 1) / TR;
@@ -599,9 +615,10 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
           &split_layer_kernel<false, true, true, 1>},
          {&split_layer_kernel<true, false, false, 1>, &split_layer_kernel<true, true, false, 1>, &split_layer_kernel<true, false, true, 1>,
           &split_layer_kernel<true, true, true, 1>}}};
-    const int first = u != nullptr;
-    kern_t kern = kerns[first][six][layout];
-    static bool attr_set_all[2][2][4] = {};
+    static const kern_t tape_kerns[2] = {&split_layer_kernel<false, false, false, 2, true>, &split_layer_kernel<true, false, false, 2, true>};
+    const int first = u != nullptr ? 1 : hid != nullptr ? 2 : 0;
+    kern_t kern = first == 2 ? tape_kerns[six] : kerns[first][six][layout];
+    static bool attr_set_all[3][2][4] = {};
     bool& attr_done = attr_set_all[first][six][layout];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -779,9 +779,13 @@ def subnet_layer(x, pc3, b3, panel1, b1, want_hidden=False, layout=0):
         raise ValueError("subnet_layer: 64-channel 3x3 layers only")
     out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
     if want_hidden:
-        if pc3.split:
-            raise ValueError("subnet_layer: the tape form runs on the fp32 Winograd layer kernel")
         hid = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+        if pc3.split:
+            if layout:
+                raise ValueError("subnet_layer: the tape form keeps NCHW maps")
+            check(L.cwfa_subnet_layer_split_tape_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), _p(hid), B, H, W,
+                                                     xbs, 64 * H * W, 64 * H * W, _stream()), "subnet_layer_split_tape")
+            return out, hid
         check(L.cwfa_subnet_layer_tape_f32(_p(x), _p(pc3.packed), _p(_dev(b3)), _p(panel1.packed), _p(_dev(b1)), _p(out), _p(hid), B, H, W,
                                            xbs, 64 * H * W, 64 * H * W, _stream()), "subnet_layer_tape")
         return out, hid

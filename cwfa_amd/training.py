@@ -52,10 +52,12 @@ def subnet_forward_train(net, u, conv_in, conv_out):
     tape = _Tape(net, conv_in, conv_out, u)
     b = ops.conv2d(u, P(conv_in), bias=conv_in.bias)
     tape.b.append(b)
-    fused = (net.n_ch == 64 and ops._split_bf16 < 2
-             and all(blk[0].bias is not None and blk[2].bias is not None for blk in _layers(net)))
+    fused = net.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None for blk in _layers(net))
+    split = ops._split_bf16 >= 2
     for blk in _layers(net):
-        if fused:       # the inference layer kernel, which also writes the hidden map it holds in registers anyway
+        if fused and split:     # the split-bf16 layer kernel in its tape form (cwfa_subnet_layer_split_tape_f32)
+            b, h = ops.subnet_layer(b, net._split3(blk[0], blk[2]), blk[0].bias, None, blk[2].bias, want_hidden=True)
+        elif fused:     # the inference layer kernel, which also writes the hidden map it holds in registers anyway
             b, h = ops.subnet_layer(b, P(blk[0]), blk[0].bias, net._panel(blk[2]), blk[2].bias, want_hidden=True)
         else:
             h = ops.conv2d(b, P(blk[0]), bias=blk[0].bias, act="elu")

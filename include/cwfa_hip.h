@@ -368,6 +368,10 @@ int64_t cwfa_subnet_layer_first_packed_bytes(void);
 int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, void* packed, void* stream);
 int cwfa_subnet_layer_first_f32(const float* u, const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                 int u_ch, int H, int W, int64_t u_bs, int64_t x_bs, int64_t y_bs, int layout, void* stream);
+/* Tape form (training forward, SURVEY.md 8f row 1 / CWFA.py:966-1006): the same launch also writes the hidden map
+ * h = ELU(conv3x3(x) + b3) [B,64,H,W] the backward needs, from the registers that hold it as the 1x1's operand.  NCHW maps. */
+int cwfa_subnet_layer_split_tape_f32(const float* x, const void* packed, const float* b3, const float* b1, float* y, float* hid, int B,
+                                     int H, int W, int64_t x_bs, int64_t y_bs, int64_t hid_bs, void* stream);
 /* layout: bit 0 = x, bit 1 = y is CHANNEL-BLOCKED, [B][8 blocks][H][W][8 channels] (same size and batch strides as NCHW, 16-byte
  * aligned), instead of NCHW planes.  The maps between the layers of one sub-network are private to it; blocked, a staging entry
  * of the kernel (8 channels of a pixel) is two 16-byte loads instead of eight 4-byte ones and the four channels a lane holds for

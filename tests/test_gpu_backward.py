@@ -166,6 +166,29 @@ def test_step_nll_backward_golden(name):
     assert_close(dict(g.named_parameters())[k0].grad, 2 * torch.from_numpy(want[k0]), TOL, "accumulated gradient")
 
 
+def test_step_nll_backward_golden_in_split_precision():
+    """The same fixture (64-channel sub-networks) with the training forward on the split-bf16 kernels -- the sub-network layers in
+    their tape form (cwfa_subnet_layer_split_tape_f32), data-gradient convolutions on the split 3x3 kernel: fp32-equivalent
+    arithmetic, same bound."""
+    from cwfa_amd import ops, training
+    fx, g = _golden_step("g13_step_grad_k0_ch64")
+    x = torch.from_numpy(fx["x"]).cuda()
+    c = [torch.from_numpy(fx["c0"]).cuda(), torch.from_numpy(fx["c1"]).cuda()]
+    ops.set_precision("split_bf16")
+    try:
+        nll, (z, low), cg = training.nll_backward(g, x, c, want_cond_grads=True)
+    finally:
+        ops.set_precision("fp32")
+    assert abs(float(nll) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    assert_close(z, fx["z"], TOL, "z")
+    want = {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}
+    got = {k: p.grad for k, p in g.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for k in sorted(want):
+        assert_close(got[k], want[k], TOL, k)
+    assert_close(cg[0], fx["gc0"], TOL, "d loss / d omega")
+
+
 def test_training_steps_reduce_the_nll():
     """Three plain gradient steps on one batch lower the NLL (end-to-end sign / scale check of the backward)."""
     from cwfa_amd import training

@@ -1644,6 +1644,30 @@ def test_split_fused_layer_is_fp32_accurate(shape):
     assert_close(y, ref, 3e-6, "split fused layer")
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96)])
+@pytest.mark.parametrize("products", [6, 1])
+def test_split_fused_layer_tape_form(shape, products):
+    """cwfa_subnet_layer_split_tape_f32 (training forward): the output is bit-identical to the plain launch and the hidden map
+    h = ELU(conv3x3(x) + b3) it also writes matches the float64 reference (bf16 operands: the restated bound)."""
+    from cwfa_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W + 7)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w3, b3 = torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g) * 0.1
+    w1, b1 = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g) * 0.1
+    F = torch.nn.functional
+    href = F.elu(F.conv2d(x.double(), w3.double(), b3.double(), padding=1))
+    ops.set_option("split_products", products)
+    try:
+        pc = ops.pack_split_layer_weight(w3.cuda(), w1.cuda())
+        y0 = ops.subnet_layer(x.cuda(), pc, b3.cuda(), None, b1.cuda())
+        y, h = ops.subnet_layer(x.cuda(), pc, b3.cuda(), None, b1.cuda(), want_hidden=True)
+    finally:
+        ops.set_option("split_products", 6)
+    assert torch.equal(y, y0)
+    assert_close(h, href, 3e-6 if products == 6 else 1e-2, "hidden map of the tape form")
+
+
 @pytest.mark.parametrize("extra", [[], ["--block-type", "GLOW"], ["--precision", "fp32"]])
 def test_bench_line_contract_at_a_small_size(extra):
     """bench.py end to end on a small workload (flows + condition nets only: the LRNN's mean branch is hard-wired to 512^2): ONE
