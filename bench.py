@@ -530,9 +530,11 @@ def forward_nll_leg(CWFA, ops, conv_inn, cond_nets, a, dev, rank, world, sync_al
 def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
     """NOT the headline: SURVEY.md 8(f) row 1 -- one training iteration over the WHOLE pyramid on one synthetic volume, in
     the reference's order (CWFA.py:865-1027): LRNN step (L2), then the four flow steps with their condition nets (inverse +
-    forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  fp32 MFMA kernels."""
+    forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  Split precision: forward
+    (sub-network layers in their tape form) and data-gradient convolutions on the split-bf16 kernels, weight gradients on the fp32
+    MFMA kernels (csrc/conv_bwd.hip); `fp32_kernels_ms_per_step` = the same iteration with every convolution on the fp32 kernels."""
     from cwfa_amd import training
-    ops.set_precision("fp32")
+    ops.set_precision("split_bf16")
     B, D, S = 1, a.depths, a.side
     gen = torch.Generator().manual_seed(17)
     gt = torch.randn(B, D, S, S, generator=gen).to(dev)
@@ -550,9 +552,18 @@ def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     n_par = sum(p.numel() for m in list(conv_inn) + list(cond_nets) for p in m.parameters() if p.requires_grad)
-    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps,
+    ops.set_precision("fp32")
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt32 = (time.perf_counter() - t0) / steps
+    return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "fp32_kernels_ms_per_step": 1e3 * dt32,
             "full_loss_per_pyramid_step": [float(v) for v in res["losses"]], "trainable_parameters": n_par,
-            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward, fp32 MFMA kernels; gradients pinned to the "
+            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; forward / data gradients on the split-bf16 kernels, weight "
+                    "gradients on the fp32 MFMA kernels; gradients pinned to the "
                     "reference's autograd by tests/test_gpu_backward.py (fixtures g13-g15)"}
 
 

@@ -500,9 +500,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
+        // run-time epilogue: the residual of n-tile nt + RLA is requested while n-tile nt is finished (one tile at a time -- as the
+        // FENCE below orders it -- every n-tile stood in the full latency of its four loads: 160 -> 1xx us for 64 -> 64 at 512 x 512)
+        constexpr int RLA = NT < 4 ? NT : 4;
+        float rv[ACT1 == EPI_RUNTIME ? NT : 1][4];
+        auto load_res = [&](int nt) {
+            const int row = row0 + wn * RW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            const unsigned po = (row < p.H && col < p.W) ? (unsigned)((row * p.W + col) * 4) + glane : OOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rv[ACT1 == EPI_RUNTIME ? nt : 0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, po, (cwave + mt * 16 + r) * plane, 0));
+        };
+        if constexpr (ACT1 == EPI_RUNTIME) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[nt][r] = 0.f;
+            if (p.o.residual) {
+#pragma unroll
+                for (int nt = 0; nt < RLA; ++nt) load_res(nt);
+            }
+            FENCE();
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int row = row0 + wn * RW + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+            if constexpr (ACT1 == EPI_RUNTIME) {
+                if (nt + RLA < NT && p.o.residual) load_res(nt + RLA);
+                FENCE();
+            }
             if constexpr (ACT1 != EPI_RUNTIME) {
                 if (outb) {
                     f32x4 o4;
@@ -520,7 +546,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                 float v = acc[mt][nt][r] + bias[r];
                 if constexpr (ACT1 == EPI_RUNTIME) {
                     v = cwfa_act(v, p.o.act, alpha);
-                    if (p.o.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, po, soff, 0));
+                    v += rv[nt][r];
                     v = cwfa_act(v, p.o.act2, alpha);
                 } else {
                     v = act_of<ACT1>(v, alpha);
