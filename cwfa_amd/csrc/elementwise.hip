@@ -776,7 +776,10 @@ __device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4&
 #ifndef CH_WAVES
 #define CH_WAVES 0       // (tuning) minimum waves per SIMD asked of the register allocator (0: none)
 #endif
-template <bool INV>
+// NS: stages the register arrays are sized for (6 covers a CAT step: five conditional affines + the trailing permutation; sized for
+// CWFA_CHAIN_MAX = 8 the kernel held 87 registers = five waves per SIMD -- with <= 80 it holds six, i.e. 1536 resident blocks, which the
+// 1536 x 2^k blocks of the 6 / 12 / 24 / 48-channel levels at 512 x 512 fill in whole rounds)
+template <bool INV, int NS = CWFA_CHAIN_MAX>
 #if CH_WAVES
 __global__ __launch_bounds__(256, CH_WAVES) void chain_rows4_kernel(
 #else
@@ -804,25 +807,25 @@ const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
     const int h = live ? hh : H - 1;
     const int64_t HW = (int64_t)H * W;
     const int n = ch.n_stages;
-    RowPos q[CWFA_CHAIN_MAX], src = INV ? RowPos{c, h} : row_gather(RowPos{c, h}, final_perm, 1);
+    RowPos q[NS], src = INV ? RowPos{c, h} : row_gather(RowPos{c, h}, final_perm, 1);
     if (ch.src_c) {                          // composed by the caller: independent loads instead of a dependent walk
 #pragma unroll
-        for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+        for (int k = 0; k < NS; ++k)
             if (k < n) q[k] = RowPos{ch.src_c[k * C + c], ch.src_h[k * H + h]};
         src = RowPos{ch.src_c[n * C + c], ch.src_h[n * H + h]};
     } else {
 #pragma unroll
-        for (int k = CWFA_CHAIN_MAX - 1; k >= 0; --k)
+        for (int k = NS - 1; k >= 0; --k)
             if (k < n) {
                 q[k] = src;
                 src = row_gather(src, ch.stage[k].perm, ch.stage[k].perm_axis);
             }
     }
     // ---- every global load of this thread, back to back
-    f4 sr[CWFA_CHAIN_MAX], tr[CWFA_CHAIN_MAX];
+    f4 sr[NS], tr[NS];
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < CWFA_CHAIN_MAX; ++k) {
+    for (int k = 0; k < NS; ++k) {
         sr[k] = tr[k] = zero;
         if (k < n) {
             const int64_t off = ((int64_t)q[k].c * H + q[k].h) * W + w4;
@@ -845,10 +848,10 @@ const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
     // ---- coefficients at the thread's OWN four columns, then the chain.  A column permutation moves the travelling values
     // between the threads of a row (through one LDS row, double-buffered: one barrier per column permutation); channel and
     // row permutations only changed which rows were loaded above.
-    f4 ev[CWFA_CHAIN_MAX], tv[CWFA_CHAIN_MAX];
+    f4 ev[NS], tv[NS];
     float ssum = 0.f;
 #pragma unroll
-    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+    for (int k = 0; k < NS; ++k)
         if (k < n) {
             f4 sv;
             stage_st4(ch.stage[k], sr[k], tr[k], sv, tv[k]);
@@ -861,7 +864,7 @@ const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
     f4 v = v0;
     int nx = 0;
 #pragma unroll
-    for (int k = 0; k < CWFA_CHAIN_MAX; ++k)
+    for (int k = 0; k < NS; ++k)
         if (k < n) {
             if (ch.stage[k].perm && ch.stage[k].perm_axis == 3) {           // uniform over the block
                 float* buf = rows + (size_t)((nx & 1) * RB + r) * W;
@@ -1078,8 +1081,12 @@ extern "C" int cwfa_chain_inv_f32(const float* z, const float* low, float* x, co
     size_t lds;
     if (chain_rows4_ok(ch, C, H, W, B, &lds, low, x, z, low_bs, x_bs, z_bs)) {
         const int RB = 1024 / W;
-        hipLaunchKernelGGL(chain_rows4_kernel<true>, dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
-                           const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
+        if (ch->n_stages <= 6)
+            hipLaunchKernelGGL((chain_rows4_kernel<true, 6>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
+                               const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
+        else
+            hipLaunchKernelGGL((chain_rows4_kernel<true, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
+                               const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
         CWFA_LAUNCH_CHECK("cwfa_chain_inv_f32");
         return CWFA_OK;
     }
@@ -1108,8 +1115,12 @@ extern "C" int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cw
     size_t lds;
     if (chain_rows4_ok(ch, C, H, W, B, &lds, x, low, z, x_bs, low_bs, z_bs)) {
         const int RB = 1024 / W;
-        hipLaunchKernelGGL(chain_rows4_kernel<false>, dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
-                           *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
+        if (ch->n_stages <= 6)
+            hipLaunchKernelGGL((chain_rows4_kernel<false, 6>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
+                               *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
+        else
+            hipLaunchKernelGGL((chain_rows4_kernel<false, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
+                               *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
         CWFA_LAUNCH_CHECK("cwfa_chain_fwd_f32");
         return CWFA_OK;
     }
