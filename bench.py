@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--no-first-composed", action="store_true", help="(ablation) the first layer of every sub-network like the other two "
                     "(K = 9 x 64) instead of its composed form")
     ap.add_argument("--no-merge-first", action="store_true", help="(ablation) every sub-network runs its own first 1x1 convolution")
+    ap.add_argument("--no-merge-omega", action="store_true", help="(ablation) every condition net runs its own conv1 / downsample launches")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
     a = ap.parse_args()
 
@@ -260,6 +261,9 @@ def main():
     if a.no_merge_first:
         from cwfa_amd import networks as _N
         _N.MERGE_FIRST_MAPS = False
+    if a.no_merge_omega:
+        from cwfa_amd import networks as _N
+        _N.MERGE_OMEGA_FIRST = False
     if a.no_couple_epilogue:
         ops.COUPLE_EPILOGUE = False
     if a.no_virtual_cat:

@@ -171,6 +171,13 @@ def inverse_pass(conv_inn, cond_nets, cond_input, mean_vols_cache, low=None, tem
     else:
         up = low
     vols = [up]
+    from .networks import omega_first_scope
+    with omega_first_scope(list(cond_nets[:S1]), cond_input):      # the steps' condition nets share their input: first convs in one launch
+        return _inverse_steps(conv_inn, cond_nets, cond_input, mean_vols_cache, up, vols, temperature, n_samples, keep_all)
+
+
+def _inverse_steps(conv_inn, cond_nets, cond_input, mean_vols_cache, up, vols, temperature, n_samples, keep_all):
+    S1 = len(conv_inn)
     for n in range(S1 - 1, -1, -1):
         g = conv_inn[n]
         cond_processed = [cond_nets[n](cond_input)[-1], mean_vols_cache[n]]
@@ -217,11 +224,13 @@ def forward_nll_pass(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache
     values.  Returns (nll float64[S-1], low-resolution volume gt_{S-1})."""
     gt = gt_volume
     rows = []
-    for n, g in enumerate(conv_inn):
-        Z, logdet, sumsq = nll_terms(g, gt, [cond_nets[n](cond_input)[-1], mean_vols_cache[n]])
-        rows.append(torch.stack([sumsq[0], logdet.to(torch.float64).sum(),
-                                 torch.tensor(float(gt.shape[0]), dtype=torch.float64, device=gt.device)]))
-        gt = Z[1]
+    from .networks import omega_first_scope
+    with omega_first_scope(list(cond_nets[:len(conv_inn)]), cond_input):
+        for n, g in enumerate(conv_inn):
+            Z, logdet, sumsq = nll_terms(g, gt, [cond_nets[n](cond_input)[-1], mean_vols_cache[n]])
+            rows.append(torch.stack([sumsq[0], logdet.to(torch.float64).sum(),
+                                     torch.tensor(float(gt.shape[0]), dtype=torch.float64, device=gt.device)]))
+            gt = Z[1]
     terms = allreduce_nll(torch.stack(rows).reshape(-1), group).view(len(conv_inn), 3)
     numel = torch.tensor([float(gt_volume[0].numel()) / 2 ** n for n in range(len(conv_inn))], dtype=torch.float64,
                          device=gt_volume.device)                    # per-sample numel of the step's input volume

@@ -36,7 +36,7 @@ class ConvOpts(C.Structure):
     _fields_ = [("bias", c_f32p), ("act", C.c_int), ("prelu_alpha", c_f32p), ("residual", c_f32p), ("res_bs", C.c_int64),
                 ("act2", C.c_int), ("in_scale", c_f32p), ("in_shift", c_f32p), ("in_affine_bs", C.c_int), ("in_add", c_f32p),
                 ("in_add_bs", C.c_int64), ("upshuffle2", C.c_int), ("in_blocked8", C.c_int), ("out_blocked8", C.c_int),
-                ("in_cat", c_f32p), ("in_cat_bs", C.c_int64), ("in_cat_from", C.c_int), ("in_cat_c1", C.c_int), ("out_stats", c_f64p)]
+                ("in_cat", c_f32p), ("in_cat_bs", C.c_int64), ("in_cat_from", C.c_int), ("in_cat_c1", C.c_int), ("out_stats", c_f64p), ("prelu_per_channel", C.c_int)]
 
 
 class Couple(C.Structure):

@@ -1016,7 +1016,7 @@ extern "C" int cwfa_conv_split_f32(const void* ws, const void* w_packed, float* 
     ConvParams& p = sp.c;
     CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add, CWFA_E_INVAL, "cwfa_conv_split_f32: the load-side prologue belongs in cwfa_split_input_f32");
     CWFA_REQUIRE(!p.o.upshuffle2 || (ks == 1 && Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv_split_f32: upshuffle2 needs ks=1, Cout=4*Co");
-    CWFA_REQUIRE(!p.o.out_stats, CWFA_E_INVAL, "cwfa_conv_split_f32: out_stats is a feature of cwfa_conv3x3_split_f32");
+    CWFA_REQUIRE(!p.o.out_stats && !p.o.prelu_per_channel, CWFA_E_INVAL, "cwfa_conv_split_f32: out_stats / prelu_per_channel are features of cwfa_conv3x3_split_f32");
     p.nchunks = (Cin + 15) / 16;
     sp.ws = ws;
     sp.CG2 = 2 * p.nchunks;
@@ -1107,7 +1107,7 @@ extern "C" int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, 
     int rc = fill_params(p, "cwfa_conv2d_f32", x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, opts);
     if (rc) return rc < 0 ? rc : CWFA_OK;
     CWFA_REQUIRE(!p.o.upshuffle2 || (ks == 1 && Cout % 4 == 0), CWFA_E_SHAPE, "cwfa_conv2d_f32: upshuffle2 needs ks=1, Cout=4*Co");
-    CWFA_REQUIRE(!p.o.out_stats, CWFA_E_INVAL, "cwfa_conv2d_f32: out_stats is a feature of cwfa_conv3x3_split_f32");
+    CWFA_REQUIRE(!p.o.out_stats && !p.o.prelu_per_channel, CWFA_E_INVAL, "cwfa_conv2d_f32: out_stats / prelu_per_channel are features of cwfa_conv3x3_split_f32");
     const int epi = classify_epilogue(p.o);
     hipStream_t st = (hipStream_t)stream;
     if (cwfa_wino_selected(ks, Cout)) return cwfa_wino_conv(x, w_packed, y, B, Cin, H, W, Cout, x_bs, y_bs, p.o, st);

@@ -427,7 +427,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.o.residual ? p.o.residual + (int64_t)b * p.o.res_bs : p.y), 0,
                                                       p.o.residual ? p.Cout * plane : 0, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.o.bias ? p.o.bias : p.y), 0, p.o.bias ? p.Cout * 4 : 0, 0x00020000);
-    const float alpha = p.o.prelu_alpha ? *p.o.prelu_alpha : 0.f;
+    const bool alpha_pc = p.o.prelu_per_channel != 0;          // (uniform) one PReLU slope per output channel
+    const float alpha = (p.o.prelu_alpha && !alpha_pc) ? *p.o.prelu_alpha : 0.f;
+    const auto rpa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(alpha_pc ? p.o.prelu_alpha : p.y), 0, alpha_pc ? p.Cout * 4 : 0, 0x00020000);
     const int cwave = ct * CT + wm * MPW * 16;      // uniform: rides in the scalar offset
     const unsigned glane = (unsigned)(4 * g) * (unsigned)plane;                           // the lane group's channel offset
     if constexpr (ACT1 == EPI_COUPLE) {
@@ -500,6 +502,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             bias[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
+        float al[4] = {alpha, alpha, alpha, alpha};
+        if (alpha_pc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                al[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rpa, (unsigned)(16 * g), (cwave + mt * 16 + r) * 4, 0));
+        }
         // run-time epilogue: the residual of n-tile nt + RLA is requested while n-tile nt is finished (one tile at a time -- as the
         // FENCE below orders it -- every n-tile stood in the full latency of its four loads: 160 -> 1xx us for 64 -> 64 at 512 x 512)
         constexpr int RLA = NT < 4 ? NT : 4;
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                 if (outb) {
                     f32x4 o4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o4[r] = act_of<ACT1>(acc[mt][nt][r] + bias[r], alpha);
+                    for (int r = 0; r < 4; ++r) o4[r] = act_of<ACT1>(acc[mt][nt][r] + bias[r], al[r]);
                     const unsigned pb = (row < p.H && col < p.W) ? (unsigned)(((g >> 1) * HW + row * p.W + col) * 32 + (g & 1) * 16) : OOB;
                     cwfa_buffer_store_b128(__builtin_bit_cast(cwfa_u32x4, o4), ry, pb, (cwave + mt * 16) * plane);   // (+ wait states: common.h)
                     continue;
@@ -545,11 +553,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
                 const int soff = (cwave + mt * 16 + r) * plane;
                 float v = acc[mt][nt][r] + bias[r];
                 if constexpr (ACT1 == EPI_RUNTIME) {
-                    v = cwfa_act(v, p.o.act, alpha);
+                    v = cwfa_act(v, p.o.act, al[r]);
                     v += rv[nt][r];
-                    v = cwfa_act(v, p.o.act2, alpha);
+                    v = cwfa_act(v, p.o.act2, al[r]);
                 } else {
-                    v = act_of<ACT1>(v, alpha);
+                    v = act_of<ACT1>(v, al[r]);
                     if (want_stats) {
                         const float vm = po != OOB ? v : 0.f;
                         st1[r] += vm;

@@ -403,11 +403,75 @@ class ResidualBlock(nn.Module):
         a = self.relu.weight
         P = self._packed.get
         c1, c2, ds = self.conv1[0], self.conv2[0], self.downsample[0]
-        o = ops.conv2d(x, P(c1), bias=c1.bias, act="prelu", prelu_alpha=a)
-        r = ops.conv2d(x, P(ds), bias=ds.bias)
+        hit = _omega_first.get(id(self)) if _omega_first is not None else None
+        if hit is not None and hit[0] is x:          # conv1 / downsample of all steps' condition nets ran as one launch (omega_first_scope)
+            o, r = hit[1], hit[2]
+        else:
+            o = ops.conv2d(x, P(c1), bias=c1.bias, act="prelu", prelu_alpha=a)
+            r = ops.conv2d(x, P(ds), bias=ds.bias)
         o = ops.conv2d(o, P(c2), bias=c2.bias, residual=r, act2="prelu", prelu_alpha=a)
         k1, k2 = self.conv3d[0], self.conv3d[3]
         return ops.conv3d_1k1(o, k1.weight, k1.bias, a, k2.weight, k2.bias)
+
+
+MERGE_OMEGA_FIRST = True     # (tuning / ablation) False: every ResidualBlock runs its own conv1 / downsample launches
+
+_omega_first = None          # inside omega_first_scope: {id(ResidualBlock): (views tensor, conv1 output, downsample output)}
+
+
+class omega_first_scope:
+    """The condition nets of all flow steps read the SAME light-field views (CWFA.py:890-899: ``cond_nets[n](cond_input)`` for every
+    n), and each ResidualBlock starts with two 3x3 convolutions of that tensor, conv1 (+ PReLU) and downsample (networks.py:212-219,
+    229-233).  Within this scope those 2 x n_steps banks run as ONE convolution 29 -> sum of their outputs on the split-bf16 3x3 kernel
+    (per-channel PReLU slopes: the blocks' slope on conv1's channels, 1.0 = identity on downsample's), each block then reads its
+    two maps as channel-slice views.  Applies in split / bf16 precision to eval-mode blocks outside autograd; anything else leaves
+    the blocks to their own launches."""
+
+    def __init__(self, nets, x):
+        self.maps = {}
+        blocks = []
+        for net in nets:
+            blk = net.subnetworks[0] if isinstance(net, cond_network) and len(net.subnetworks) == 1 else None
+            if not isinstance(blk, ResidualBlock):
+                return
+            blocks.append(blk)
+        if not (MERGE_OMEGA_FIRST and len(blocks) >= 2 and ops._split_bf16 >= 2 and torch.is_tensor(x) and x.dim() == 4 and x.is_cuda):
+            return
+        cin = blocks[0].conv1[0].in_channels
+        total = 2 * sum(b.out_channels for b in blocks)
+        if (x.shape[1] != cin or any(b.training or b.conv1[0].in_channels != cin or b.conv1[0].bias is None or b.downsample[0].bias is None
+                                     or not isinstance(b.relu, nn.PReLU) or b.relu.weight.numel() != 1 for b in blocks)
+                or AG.tracking(x, *blocks) or (total + 64) * x.shape[2] * x.shape[3] * 4 >= 2 ** 31):
+            return
+        tensors = [t for b in blocks for t in (b.conv1[0].weight, b.conv1[0].bias, b.downsample[0].weight, b.downsample[0].bias, b.relu.weight)]
+        key = tuple((id(b),) for b in blocks) + tuple((t._version, t.data_ptr()) for t in tensors) + (ops.pack_epoch(),)
+        hit = getattr(blocks[0], "_cwfa_omega_first", None)          # cached ON the first block (dies with it)
+        if hit is None or hit[0] != key:
+            w = torch.cat([c.weight.detach() for b in blocks for c in (b.conv1[0], b.downsample[0])], 0).contiguous()
+            bias = torch.cat([c.bias.detach() for b in blocks for c in (b.conv1[0], b.downsample[0])]).contiguous()
+            slopes = torch.cat([v for b in blocks for v in (b.relu.weight.detach().reshape(1).expand(b.out_channels),
+                                                            torch.ones(b.out_channels, dtype=torch.float32, device=w.device))]).contiguous()
+            pc = ops.pack_conv_weight(w)
+            if not (pc.split and pc.ks == 3):
+                return
+            hit = (key, pc, bias, slopes)
+            object.__setattr__(blocks[0], "_cwfa_omega_first", hit)
+        y = ops.conv2d(x, hit[1], bias=hit[2], act="prelu", prelu_alpha=hit[3])
+        off = 0
+        for b in blocks:
+            C_ = b.out_channels
+            self.maps[id(b)] = (x, y[:, off:off + C_], y[:, off + C_:off + 2 * C_])
+            off += 2 * C_
+
+    def __enter__(self):
+        global _omega_first
+        self.prev, _omega_first = _omega_first, (self.maps or None)
+        return self
+
+    def __exit__(self, *exc):
+        global _omega_first
+        _omega_first = self.prev
+        return False
 
 
 class cond_network(nn.Module):

@@ -469,7 +469,12 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         o.bias = _dev(bias, "bias").data_ptr()
     o.act, o.act2 = _lib.ACT[act], _lib.ACT[act2]
     if prelu_alpha is not None:
-        o.prelu_alpha = _dev(prelu_alpha, "prelu_alpha").data_ptr()
+        prelu_alpha = _dev(prelu_alpha, "prelu_alpha")
+        o.prelu_alpha = prelu_alpha.data_ptr()
+        if prelu_alpha.numel() != 1:             # one slope per output channel (1.0 = no activation there): split-bf16 3x3 kernel only
+            if prelu_alpha.numel() != pc.cout or not prelu_alpha.is_contiguous() or not (pc.split and pc.ks == 3):
+                raise ValueError("conv2d: per-channel PReLU slopes need [Cout] contiguous values and the split-bf16 3x3 kernel")
+            o.prelu_per_channel = 1
     elif "prelu" in (act, act2):
         raise ValueError("conv2d: PReLU needs prelu_alpha")
     if residual is not None:

@@ -218,6 +218,10 @@ typedef struct {
                                  launch ADDS (sum y, sum y^2) of its output over (B,H,W) per channel -- the train-mode
                                  BatchNorm statistics of the layer that follows the convolution (unet.py:99-107), taken
                                  from the accumulators instead of a second pass over y (cwfa_channel_stats_f32)       */
+    int prelu_per_channel;    /* cwfa_conv3x3_split_f32 only: prelu_alpha points to Cout slopes, one per output channel
+                                 (slope 1.0 = no activation on that channel): several filter banks that read the same
+                                 input -- conv1 (+ PReLU) and downsample (plain) of the condition nets' ResidualBlocks,
+                                 networks.py:212-219,229-233 -- run as ONE convolution                                 */
 } cwfa_conv_opts;
 
 int cwfa_conv2d_f32(const float* x, const float* w_packed, float* y, int B, int Cin, int H, int W, int Cout, int ks,

@@ -978,6 +978,60 @@ def test_baseline_small_configs_inverse_vs_oracle(cfg):
             assert_close(a, b, TOL, f"{what}, {prec}, level {i}")
 
 
+def test_per_channel_prelu_slopes_in_the_split_3x3_epilogue():
+    """cwfa_conv_opts.prelu_per_channel: one slope per output channel (1.0 = identity) against float64 torch -- the form in which
+    conv1 (+ PReLU) and downsample (plain) of several condition nets run as one convolution."""
+    from cwfa_amd import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 29, 37, 45, generator=g)
+    w, b = torch.randn(180, 29, 3, 3, generator=g) / 16, torch.randn(180, generator=g) * 0.1
+    slopes = torch.where(torch.arange(180) % 24 < 12, torch.tensor(0.25), torch.tensor(1.0))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = torch.where(ref > 0, ref, ref * slopes.double().view(1, -1, 1, 1))
+    ops.set_precision("split_bf16")
+    try:
+        pc = ops.pack_conv_weight(w.cuda())
+        assert pc.split
+        y = ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=slopes.cuda())
+        with pytest.raises(ValueError):
+            ops.conv2d(x.cuda(), pc, bias=b.cuda(), act="prelu", prelu_alpha=slopes[:7].cuda())
+    finally:
+        ops.set_precision("fp32")
+    assert_close(y, ref, 3e-6, "per-channel PReLU")
+
+
+def test_condition_nets_with_merged_first_convolutions():
+    """networks.omega_first_scope: conv1 / downsample of the four steps' condition nets as one launch (split precision) against the
+    blocks' own launches -- same values up to the kernels' rounding (the separate launches take other tilings / the fp32 Winograd
+    kernel for the small banks), and the scope leaves train-mode blocks and other inputs alone."""
+    from cwfa_amd import networks as N, ops
+    torch.manual_seed(3)
+    nets = [N.cond_network(29, c, 1).cuda().eval() for c in (48, 24, 12, 6)]
+    x = torch.randn(1, 29, 96, 128).cuda()
+    ops.set_precision("split_bf16")
+    try:
+        with torch.no_grad():
+            ref = [net(x)[-1] for net in nets]
+            rec = []
+            with N.omega_first_scope(nets, x) as sc:
+                assert len(sc.maps) == 4
+                got = [net(x)[-1] for net in nets]
+                other = nets[0](x.clone())[-1]              # another tensor object: the block runs its own launches
+            with N.omega_first_scope(nets[:1], x) as sc1:   # a single net: nothing to merge
+                assert not sc1.maps
+            nets[1].train()
+            with N.omega_first_scope(nets, x) as sc2:       # a train-mode block (Dropout3d live): the scope stays out
+                assert not sc2.maps
+            nets[1].eval()
+    finally:
+        ops.set_precision("fp32")
+    assert N._omega_first is None
+    for a, b in zip(got, ref):
+        assert_close(a, b, 1e-5, "merged first convolutions of the condition nets")
+    assert torch.equal(other, ref[0])
+
+
 @pytest.mark.parametrize("block_type", ["GLOW", "AI1", "RNVP", "GIN"])
 def test_full_size_block_types_vs_oracle(block_type):
     """The block types ``--INN_block_type`` selects besides CAT (networks.py:289-297; north_star names GLOW and AI1), at
