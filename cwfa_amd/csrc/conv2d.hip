@@ -1045,6 +1045,10 @@ extern "C" int cwfa_set_option(const char* name, int value) {
         g_cwfa_wino_2d = value;
         return CWFA_OK;
     }
+    if (strcmp(name, "wgrad_split") == 0) {         // 1: the 3x3 weight gradient on the bf16 matrix cores in split arithmetic (conv_bwd.hip)
+        g_cwfa_wgrad_split = value != 0;
+        return CWFA_OK;
+    }
     if (strcmp(name, "wgrad_rows") == 0) {          // 0: the 3x3 weight gradient always takes its first (register-staged) form
         g_cwfa_wgrad_rows = value;
         return CWFA_OK;

@@ -416,8 +416,207 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_kernel(WgParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 3x3 weight gradient on the bf16 matrix cores in the fp32-equivalent split arithmetic of the forward kernels (every fp32 operand =
+// three bf16 pieces exactly, six partial products, fp32 accumulation; SIX = false: plain bf16 operands).  Training in split /
+// bf16 precision.
+//   GEMM: M = 64 couts (A = dy), N = 64 cins x 9 taps (B = x), K = pixels -- v_mfma_f32_16x16x32_bf16 takes 32 PIXELS OF ONE IMAGE
+//   ROW per instruction; lane group g holds pixels 8g .. 8g+7 of both operands, i.e. one aligned 16-byte LDS read each.
+//   A tap's kx shift would misalign the x read by 2 bytes (ds_read_b128 at a 2-byte offset: 11x slower, tools/probe/lds_unaligned),
+//   so the shift is put on dy instead and paid at staging time: dy sits in LDS in THREE copies, shifted by +1 / 0 / -1 pixel
+//   (a staging thread holds its eight pixels and the two neighbours and packs three windows of the ten); the ky shift is a row
+//   of the x ring.  Zero padding = the range check of the buffer loads (x) / explicit out-of-range offsets (dy beyond the row).
+//   A block (8 waves) owns 64 couts x 64 cins and walks UNITS = (sample, 32-pixel column, segment of SEG rows) top to bottom,
+//   one dy row per step: x rows live in a four-slot LDS ring (rows y-1, y, y+1 in use, y+2 being written), dy rows in two
+//   buffers; wave (mt = wave & 3, nh = wave >> 2) holds the 16 co x 32 ci x 9 taps accumulators (72 registers).  Per step and
+//   wave: 9 + 18 ds_read_b128, 108 MFMAs, one barrier.  Waves 0..3 stage dy (8 + 2 pixels per thread, the bias gradient is the
+//   running sum of what they load), waves 4..7 stage x (8 pixels per thread); the global loads of step y + 1 are issued before
+//   the MFMAs of step y and split / stored behind them.
+//   Partials per worker + wgrad_reduce_kernel in a fixed order, as for the fp32 forms: deterministic.
+namespace ws {
+constexpr int SEG = 32;                       // rows per unit
+constexpr int DYROW = 64 + 16;                // bytes per (copy, piece, co): 32 bf16 + pad (5 x 16: conflict-free b128 reads)
+constexpr int DYPLANE = 64 * DYROW, DYBUF = 9 * DYPLANE;
+constexpr int XROW = 4 * 64 + 16;             // bytes per (piece, ci): four ring rows of 32 bf16 + pad (17 x 16)
+constexpr int XPLANE = 64 * XROW, XBUF = 3 * XPLANE;
+constexpr int LDS_BYTES = 2 * DYBUF + XBUF;   // 144 384
+}  // namespace ws
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool SIX>
+__device__ __forceinline__ void wsplit3(float v, __bf16& a1, __bf16& a2, __bf16& a3) {
+    a1 = (__bf16)v;
+    a2 = a3 = (__bf16)0.f;
+    if constexpr (SIX) {
+        const float r1 = v - (float)a1;
+        a2 = (__bf16)r1;
+        a3 = (__bf16)(r1 - (float)a2);
+    }
+}
+
+template <bool SIX>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
+    using namespace ws;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wave & 3, nh = wave >> 2;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int HW = p.H * p.W;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NQ = SIX ? 3 : 1;
+    const bool is_dy = wave < 4;                              // (uniform) staging role
+    const int ch = (tid & 255) >> 2, grp = tid & 3;           // channel of the tile, group of eight pixels
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    for (int unit = blockIdx.x; unit < p.nstrips; unit += gridDim.x) {
+        const int b = unit / (p.sy * p.sx), rem = unit - b * (p.sy * p.sx);
+        const int y0 = (rem / p.sx) * SEG, c0 = (rem % p.sx) * 32;
+        const int y1 = min(p.H, y0 + SEG);
+        // this thread's staging source: dy threads read channel co0 + ch of dy, x threads channel ci0 + ch of x
+        const int cvalid = is_dy ? min(64, p.Cout - co0) : min(64, p.Cin - ci0);
+        const float* src = is_dy ? p.dy + (int64_t)b * p.dy_bs + (int64_t)co0 * HW : p.x + (int64_t)b * p.x_bs + (int64_t)ci0 * HW;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, cvalid * HW * 4, 0x00020000);
+        const int px = c0 + grp * 8;
+        float e[10];                                           // [0] = pixel px - 1, [1..8] = px .. px + 7, [9] = px + 8 (dy only)
+        auto load_row = [&](int y) {
+            const bool rowok = y >= 0 && y < p.H && ch < cvalid;
+            const unsigned base = (unsigned)((ch * HW + y * p.W + px) * 4);
+            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (rowok && px < p.W) ? base : OOB, 0, 0));
+            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (rowok && px + 4 < p.W) ? base + 16 : OOB, 0, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[1 + j] = lo[j];
+                e[5 + j] = hi[j];
+            }
+            if (is_dy) {
+                e[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rowok && px >= 1 && px - 1 < p.W) ? base - 4 : OOB, 0, 0));
+                e[9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rowok && px + 8 < p.W) ? base + 32 : OOB, 0, 0));
+            }
+        };
+        // split the loaded row and store it: x -> ring slot `slot`; dy -> buffer `buf`, three shifted copies; `count`: add to the bias sum
+        auto store_row = [&](int slot, int buf, bool count) {
+            if (is_dy) {
+                __bf16 pc[3][10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) wsplit3<SIX>(e[i], pc[0][i], pc[1][i], pc[2][i]);
+                if (count) {
+#pragma unroll
+                    for (int i = 1; i <= 8; ++i) bsum += e[i];
+                }
+                char* dst = lds + buf * DYBUF + ch * DYROW + grp * 16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)                   // copy s (= kx): element k <-> dy[px0 + k + 1 - s]
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        bf16x8 v;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = pc[q][j + 2 - s];
+                        *reinterpret_cast<bf16x8*>(dst + (s * 3 + q) * DYPLANE) = v;
+                    }
+            } else {
+                __bf16 pc[3][8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wsplit3<SIX>(e[1 + i], pc[0][i], pc[1][i], pc[2][i]);
+                char* dst = lds + 2 * DYBUF + ch * XROW + slot * 64 + grp * 16;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = pc[q][j];
+                    *reinterpret_cast<bf16x8*>(dst + q * XPLANE) = v;
+                }
+            }
+        };
+        // ---- fill: x rows y0 - 1, y0, y0 + 1 -> slots 0, 1, 2; dy row y0 -> buffer 0
+        __syncthreads();                                       // (the previous unit's last reads)
+        if (is_dy) {
+            load_row(y0);
+            store_row(0, 0, true);
+        } else {
+            load_row(y0 - 1);
+            store_row(0, 0, false);
+            load_row(y0);
+            store_row(1, 0, false);
+            load_row(y0 + 1);
+            store_row(2, 0, false);
+        }
+        __syncthreads();
+        for (int y = y0; y < y1; ++y) {
+            const int j = y - y0;
+            // next step's rows: dy row y + 1 -> buffer (j + 1) & 1, x row y + 2 -> slot (j + 3) & 3 (free: last read at step y - 1)
+            load_row(is_dy ? y + 1 : y + 2);
+            const char* dyb = lds + (j & 1) * DYBUF + (mt * 16 + c16) * DYROW + g * 16;
+            const char* xb = lds + 2 * DYBUF + ((nh * 2) * 16 + c16) * XROW + g * 16;
+            bf16x8 A[3][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) A[s][q] = *reinterpret_cast<const bf16x8*>(dyb + (s * 3 + q) * DYPLANE);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int slot = (j + ky) & 3;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    bf16x8 Bq[3];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) Bq[q] = *reinterpret_cast<const bf16x8*>(xb + q * XPLANE + n * 16 * XROW + slot * 64);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        f32x4 c = acc[n][ky * 3 + kx];
+                        if constexpr (SIX) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][2], Bq[0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][1], Bq[1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][0], Bq[2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][1], Bq[0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][0], Bq[1], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][0], Bq[0], c, 0, 0, 0);
+                        acc[n][ky * 3 + kx] = c;
+                    }
+                }
+            }
+            store_row((j + 3) & 3, (j + 1) & 1, y + 1 < y1);
+            __syncthreads();
+        }
+    }
+
+    // ---- bias gradient: the four pixel groups of a dy channel are four adjacent lanes
+    if (p.bpart && blockIdx.z == 0) {
+        float t = bsum + __shfl_xor(bsum, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        if (is_dy && grp == 0 && co0 + ch < p.Cout) p.bpart[(int64_t)blockIdx.x * p.Cout + co0 + ch] = t;
+    }
+    // accumulator register r of tile (n, tap): co = co0 + 16 mt + 4 g + r, ci = ci0 + 16 (2 nh + n) + c16
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.Cin * 9;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ci = ci0 + (nh * 2 + n) * 16 + c16;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + mt * 16 + 4 * g + r;
+            if (co < p.Cout) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) out[((int64_t)co * p.Cin + ci) * 9 + t] = acc[n][t][r];
+            }
+        }
+    }
+}
+
 }  // namespace
-int g_cwfa_wgrad_rows = 1;   // 3x3: the LDS-DMA / row-paired form when the image rows are 16-byte aligned (option "wgrad_rows")
+int g_cwfa_wgrad_rows = 1;
+int g_cwfa_wgrad_split = 0;  // 3x3: the split-bf16 form on the bf16 matrix cores (option "wgrad_split"; ops.set_precision sets it)
+extern int g_cwfa_split_products;   // 3x3: the LDS-DMA / row-paired form when the image rows are 16-byte aligned (option "wgrad_rows")
 namespace {
 
 int wgrad_workers(int B, int H, int W, int Cout, int Cin, int ks) {
@@ -511,6 +710,32 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
+    if (ks == 3 && g_cwfa_wgrad_split && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) && cwfa_aligned16(dy) &&
+        (int64_t)H * W % 4 == 0) {
+        // units = (sample, 32-pixel column, segment of ws::SEG rows); the same workers and partial banks as the fp32 forms
+        p.sx = (W + 31) / 32;
+        p.sy = (H + ws::SEG - 1) / ws::SEG;
+        p.nstrips = B * p.sy * p.sx;
+        const bool six = g_cwfa_split_products != 1;
+        auto kern = six ? &conv_wgrad_split_kernel<true> : &conv_wgrad_split_kernel<false>;
+        static bool attr_s[2] = {false, false};
+        if (!attr_s[six]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ws::LDS_BYTES);
+            CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_s[six] = true;
+        }
+        dim3 sgrid(min(workers, p.nstrips), grid.y, grid.z);
+        hipLaunchKernelGGL(kern, sgrid, dim3(512), ws::LDS_BYTES, st, p);
+        CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw, n, (int)sgrid.x, beta);
+        CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+        if (db) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p.bpart, db, (int64_t)Cout,
+                               (int)sgrid.x, beta);
+            CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
+        }
+        return CWFA_OK;
+    }
     const bool rows_form = ks == 3 && g_cwfa_wgrad_rows && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) &&
                            cwfa_aligned16(dy) && (int64_t)H * W % 4 == 0;
     if (rows_form) {

@@ -11,6 +11,7 @@ static inline bool cwfa_wino_selected(int ks, int Cout) { return ks == 3 && Cout
 // "winograd_2d" = v: layers with more than 64 and at least v output channels take the 2-D F(2x2,3x3) kernel
 // (conv_wino2d.hip); 0 = never
 extern int g_cwfa_wgrad_rows;    // conv_bwd.hip
+extern int g_cwfa_wgrad_split;   // conv_bwd.hip
 extern int g_cwfa_wino_2d;
 static inline bool cwfa_wino2d_selected(int Cout) { return g_cwfa_wino_2d != 0 && Cout > 64 && Cout >= g_cwfa_wino_2d; }
 int64_t cwfa_wino2d_packed_floats(int Cout, int Cin);

@@ -1265,6 +1265,7 @@ def set_precision(mode):
         raise ValueError(f"set_precision: unknown mode {mode!r}")
     set_option("split_products", 1 if mode == "bf16" else 6)
     set_option("split_bf16", 0 if mode == "fp32" else 2)
+    set_option("wgrad_split", 0 if mode == "fp32" else 1)        # training: 3x3 weight gradients in the same arithmetic (csrc/conv_bwd.hip)
 
 
 def copy_channels(src, dst):

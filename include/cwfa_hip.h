@@ -56,6 +56,8 @@ const char* cwfa_last_error(void);
  *   "split_products"    : 6 (default): the split-bf16 kernels form every fp32 product from six bf16 products
  *                         (fp32-equivalent); 1: plain bf16 operands (BASELINE.json configs[4]).
  *   "wgrad_rows"        : 0: the 3x3 weight gradient always takes its first (register-staged) form.
+ *   "wgrad_split"       : 1: the 3x3 weight gradient (16-byte aligned rows) runs on the bf16 matrix cores in the split
+ *                         arithmetic of "split_products" (training in split / bf16 precision); 0 (default): fp32 MFMA.
  *   "split3x3_xcd_map"  : 0: (ablation) blocks of the split 3x3 kernel in plain (spatial tile, cout tile) order instead of
  *                         the XCD-aware one.
  *   "split3x3_rows16"   : 0: (ablation) the 64-channel tiling of the split 3x3 kernel always on 8-row tiles.

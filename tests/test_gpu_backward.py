@@ -51,6 +51,41 @@ def test_conv_weight_gradient_vs_autograd(cfg):
     assert torch.equal(got, ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks))
 
 
+@pytest.mark.parametrize("cfg", [  # (B, Cin, Cout, H, W): W % 4 == 0 (else the fp32 form runs)
+    (1, 64, 64, 64, 64), (2, 64, 64, 37, 44), (1, 70, 130, 19, 36), (1, 8, 8, 6, 4), (1, 64, 64, 5, 100), (3, 29, 48, 16, 32),
+    (1, 64, 64, 33, 32), (1, 128, 64, 70, 96), (2, 16, 96, 65, 8)])
+def test_conv_weight_gradient_split_form_vs_autograd(cfg):
+    """The 3x3 weight gradient on the bf16 matrix cores in split arithmetic (option "wgrad_split", what set_precision("split_bf16")
+    selects): same float64 reference and bound as the fp32 forms -- segment borders (SEG = 32 rows), ragged right edges, partial
+    channel tiles, several samples, accumulation into an existing buffer, strided operands, determinism."""
+    from cwfa_amd import ops
+    B, Cin, Cout, H, W = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, padding=1) * dy.double()).sum().backward()
+    ops.set_option("wgrad_split", 1)
+    try:
+        got, gb = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3, want_bias=True)
+        base = torch.randn(Cout, Cin, 3, 3, generator=g)
+        xb = torch.randn(B, Cin + 3, H, W, generator=g)
+        xb[:, 2:2 + Cin] = x
+        bb = torch.randn(Cout, generator=g)
+        acc, accb = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), 3, out=base.cuda().clone(), accumulate=True, bias_out=bb.cuda().clone())
+        again = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3)
+        ops.set_option("wgrad_split", 0)
+        fp32 = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3)
+    finally:
+        ops.set_option("wgrad_split", 0)
+    assert_close(got, w.grad, 3e-6, f"dW {cfg}")
+    assert_close(gb, dy.double().sum((0, 2, 3)), TOL, f"db {cfg}")
+    assert_close(acc, w.grad + base.double(), 3e-6, f"dW accumulate {cfg}")
+    assert_close(accb, dy.double().sum((0, 2, 3)) + bb.double(), TOL, f"db accumulate {cfg}")
+    assert torch.equal(got, again)
+    assert_close(got, fp32, 3e-6, "split form vs fp32 form")
+
+
 def test_elu_backward():
     from cwfa_amd import ops
     g0 = torch.Generator().manual_seed(3)
