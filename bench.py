@@ -535,8 +535,9 @@ def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
     """NOT the headline: SURVEY.md 8(f) row 1 -- one training iteration over the WHOLE pyramid on one synthetic volume, in
     the reference's order (CWFA.py:865-1027): LRNN step (L2), then the four flow steps with their condition nets (inverse +
     forward + backward of 0.40984 * mse + 0.59016 * NLL); gradients computed, no optimiser update.  Split precision: forward
-    (sub-network layers in their tape form) and data-gradient convolutions on the split-bf16 kernels, weight gradients on the fp32
-    MFMA kernels (csrc/conv_bwd.hip); `fp32_kernels_ms_per_step` = the same iteration with every convolution on the fp32 kernels."""
+    (sub-network layers in their tape form), data-gradient convolutions and the 3x3 weight gradients on the bf16 matrix cores in the
+    fp32-equivalent split arithmetic (csrc/conv_bwd.hip: conv_wgrad_split_kernel); 1x1 / 1x7 weight gradients and the Conv3d backward on
+    the fp32 kernels; `fp32_kernels_ms_per_step` = the same iteration with every convolution on the fp32 kernels."""
     from cwfa_amd import training
     ops.set_precision("split_bf16")
     B, D, S = 1, a.depths, a.side
@@ -566,8 +567,8 @@ def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
     dt32 = (time.perf_counter() - t0) / steps
     return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "fp32_kernels_ms_per_step": 1e3 * dt32,
             "full_loss_per_pyramid_step": [float(v) for v in res["losses"]], "trainable_parameters": n_par,
-            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; forward / data gradients on the split-bf16 kernels, weight "
-                    "gradients on the fp32 MFMA kernels; gradients pinned to the "
+            "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; forward, data gradients and 3x3 weight gradients in "
+                    "split-bf16 arithmetic (fp32-equivalent), 1x1 / 1x7 weight gradients and the Conv3d backward on the fp32 kernels; gradients pinned to the "
                     "reference's autograd by tests/test_gpu_backward.py (fixtures g13-g15)"}
 
 

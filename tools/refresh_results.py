@@ -31,7 +31,7 @@ for bt in ("GLOW", "AI1"):
         others.append(f"{bt} {g['value']:.1f} volumes/s ({g['ms_per_step']:.1f} ms; forward NLL {g.get('forward_nll', {}).get('value', float('nan')):.1f})")
 fw = d.get("forward_nll", {})
 block = f"""<!-- RESULTS:BEGIN (tools/refresh_results.py {TAG}) -->
-| {TAG.replace('_', ' ')} (split-bf16 fp32-equivalent convolutions on `v_mfma_f32_16x16x32_bf16`, fused split layer, channel-blocked sub-network maps, 16-byte chain kernels) | **{d['value']:.1f}** | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` (the UNet's 3×3 convolutions without a skip add, {r['launches_timed'] // d['steps']} launches per volume, {100 * r['share_of_conv_time']:.0f} % of the conv time) | {r['algorithmic_tflops']:.0f} algorithmic = {r['achieved']:.0f} issued of 2500 bf16: **{r['frac']:.2f}** | in-path chain {dw['achieved']:.0f} ({dw['frac']:.2f}); largest level {dw['largest_level']['GBps']:.0f} ({dw['largest_level']['GBps'] / 8000:.2f}) |
+| {TAG.replace('_', ' ')} (round 3: + split-bf16 Conv3d, BatchNorm statistics in the conv epilogue, composed first layers, merged first convolutions, seven-wave chain kernels) | **{d['value']:.1f}** | {d['ms_per_step']:.2f} | `{r['kernel'].split(' (')[0]}` (the UNet's 3×3 convolutions without a skip add and the merged first convolution of the four condition nets, {r['launches_timed'] // d['steps']} launches per volume, {100 * r['share_of_conv_time']:.0f} % of the conv time) | {r['algorithmic_tflops']:.0f} algorithmic = {r['achieved']:.0f} issued of 2500 bf16: **{r['frac']:.2f}** | in-path chain {dw['achieved']:.0f} ({dw['frac']:.2f}); largest level {dw['largest_level']['GBps']:.0f} ({dw['largest_level']['GBps'] / 8000:.2f}) |
 
 Same line: runner-up `{r2['kernel'].split(' (')[0]}` {r2['algorithmic_tflops']:.0f} TF/s algorithmic, frac **{r2['frac']:.2f}** ({1e3 * r2['avg_launch_ms']:.1f} µs per launch, 60 launches per volume); plain fp32 MFMA kernels (`fp32_mfma`) {d['fp32_mfma']['value']:.1f} volumes/s; bf16 configuration (`bf16`, BASELINE configs[4]) {d['bf16']['value']:.1f}; forward NLL (configs[3], batch 4 per GPU) {fw.get('value', float('nan')):.1f} volumes/s with its chain at {fw.get('chain_fwd', {}).get('frac', float('nan')):.2f} of the HBM peak; training iteration {d['experiment_train_step']['value']:.2f} volumes/s.  Other block types (`bench.py --block-type`, `profiles/{TAG}_bench_<type>.json`): {'; '.join(others)}.  Standalone wavelet kernels (not launched by the path): four inverse depth-Haar levels {dw['standalone_haar']['achieved']:.0f} GB/s ({dw['standalone_haar']['frac']:.2f}); one-pass 2×2×2 Haar tile {dw['haar3d_tile']['achieved']:.0f} GB/s ({dw['haar3d_tile']['frac']:.2f}).
 
