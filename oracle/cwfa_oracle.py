@@ -311,17 +311,28 @@ def _unet_convblock(sd: SD, p: str, x: Tensor, train: bool) -> Tensor:
     return x
 
 
-def unet(sd: SD, x: Tensor, p: str = "", depth: int = 3, train: bool = False) -> Tensor:
-    """UNet.forward with drop_out=0 (dropout2d is stochastic, unet.py:80,86), skip **add**, upconv.  unet.py:72-91,161-195."""
-    skips = []
+def unet(sd: SD, x: Tensor, p: str = "", depth: int = 3, train: bool = False, drop_u=None, drop_p: float = 0.0) -> Tensor:
+    """UNet.forward, skip **add**, upconv.  unet.py:72-91,161-195.  ``F.dropout2d(x, self.drop_out)`` (unet.py:80 after every
+    pooling, :86 after every up block; functional default training=True, so it is live in eval mode too) is stochastic: by default
+    it is left out (drop_out = 0); with ``drop_u`` -- one uniform [B, C] tensor per site in call order -- it is applied as what it
+    computes, x * (u >= p) / (1 - p) per (sample, channel), so a test can hand both sides the same draws."""
+    skips, site = [], [0]
+
+    def drop(t):
+        if drop_u is None:
+            return t
+        u = drop_u[site[0]]
+        site[0] += 1
+        return t * ((u >= drop_p).to(t.dtype) / (1.0 - drop_p)).view(t.shape[0], t.shape[1], 1, 1)
+
     for i in range(depth):
         x = _unet_convblock(sd, f"{p}down_path.{i}.", x, train)
         if i != depth - 1:
             skips.append(x)
-            x = F.adaptive_max_pool2d(x, x.shape[-1] // 2)                      # unet.py:79
+            x = drop(F.adaptive_max_pool2d(x, x.shape[-1] // 2))                # unet.py:79-80
     for i in range(depth - 1):
         up = F.conv_transpose2d(x, sd[f"{p}up_path.{i}.up.weight"], sd.get(f"{p}up_path.{i}.up.bias"), stride=2)
-        x = _unet_convblock(sd, f"{p}up_path.{i}.conv_block.", up + skips[-i - 1], train)
+        x = drop(_unet_convblock(sd, f"{p}up_path.{i}.conv_block.", up + skips[-i - 1], train))      # unet.py:85-86
     x = F.conv2d(x, sd[p + "last.0.weight"], sd.get(p + "last.0.bias"))
     return F.prelu(x, sd[p + "last.1.weight"])
 

@@ -794,6 +794,47 @@ def test_unet_golden(bias):
     assert_close(u(x[:1]), fx["y_train_b1"], TOL, "train B=1")
 
 
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("prec", ["fp32", "split_bf16"])
+def test_unet_with_live_dropout2d_vs_oracle(mode, prec):
+    """``F.dropout2d(x, self.drop_out)`` of the UNet (unet.py:80,86: live in train AND eval mode) with the SAME uniform draws on both
+    sides: the HIP path forms the factor (u >= p) / (1 - p) in cwfa_bn_finish_f32 and applies it on the next convolution's load
+    side (skip tensor included); the oracle multiplies where the reference calls dropout2d.  Golden weights of g11, p = 0.3."""
+    from cwfa_amd import ops, unet as U
+    from oracle import cwfa_oracle as O
+    fx = load_golden("g11_unet_bias1")
+    net = U.UNet(5, 4, depth=3, wf=3, drop_out=0.3, use_bias=True, skip_conn=True, up_mode="upconv", batch_norm=True)
+    net.load_state_dict(sd_of(fx))
+    net = net.cuda()
+    net.train() if mode == "train" else net.eval()
+    x = torch.from_numpy(fx["x"])
+    B = x.shape[0]
+    chans = [d.block[0].out_channels for d in list(net.down_path)[:-1]] + [u.conv_block.block[0].out_channels for u in net.up_path]
+    g = torch.Generator().manual_seed(9)
+    draws = [torch.rand(B, c, generator=g) for c in chans]
+    assert any(bool((d < 0.3).any()) for d in draws)
+    flat = torch.cat([d.reshape(-1) for d in draws]).cuda()
+
+    class Pool(U._DrawPool):                                   # the forward's one torch.rand launch replaced by the given draws
+        def __init__(self, n, device):
+            assert n == flat.numel()
+            self.u, self.pos = flat, 0
+
+    orig = U._DrawPool
+    U._DrawPool = Pool
+    ops.set_precision(prec)
+    try:
+        with torch.no_grad():
+            y = net(x.cuda())
+    finally:
+        U._DrawPool = orig
+        ops.set_precision("fp32")
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()} if mode == "eval" else sd_of(fx)
+    with torch.no_grad():
+        ref = O.unet(sd, x, depth=3, train=(mode == "train"), drop_u=draws, drop_p=0.3)
+    assert_close(y, ref, TOL, f"UNet with dropout2d, {mode}, {prec}")
+
+
 def test_convnext_attention_golden():
     from cwfa_amd import networks as N
     fx = load_golden("g11_convnext")
