@@ -835,6 +835,21 @@ def test_unet_with_live_dropout2d_vs_oracle(mode, prec):
     assert_close(y, ref, TOL, f"UNet with dropout2d, {mode}, {prec}")
 
 
+def test_drop_path_is_per_sample_bernoulli_scaling():
+    """networks.drop_path (networks.py:370-385: x / keep * floor(keep + U) per sample): every sample is either dropped or scaled by
+    exactly 1 / keep, the kept fraction is Bernoulli(keep), eval mode / p = 0 return the input itself."""
+    from cwfa_amd import networks as N
+    torch.manual_seed(4)
+    x = torch.randn(400, 3, 4, 8).cuda()
+    y = N.drop_path(x, 0.25, True)
+    ratio = (y / x).reshape(400, -1)
+    kept = ratio[:, 0] != 0
+    assert torch.equal(y[~kept], torch.zeros_like(y[~kept]))
+    assert torch.equal(y[kept], x[kept] * torch.tensor(1.0, device="cuda").div(0.75))
+    assert 0.65 < float(kept.float().mean()) < 0.85                       # Bernoulli(0.75), n = 400: 6 sigma = 0.13
+    assert N.drop_path(x, 0.25, False) is x and N.drop_path(x, 0.0, True) is x
+
+
 def test_convnext_attention_golden():
     from cwfa_amd import networks as N
     fx = load_golden("g11_convnext")
