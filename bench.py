@@ -59,8 +59,9 @@ def family(key):
         act1 = 2 if (plain and act == "prelu") else 0 if (plain and not act and not key[7]) else -1
         if tag.endswith("couple+split"):
             act1 = -2
-        mpw = 4 if cout > 128 else 2 if cout > 64 else 1
-        wm = 4 if cout > 32 else 2 if cout > 16 else 1                             # channel groups per block: narrow tilings for small banks
+        # (m-tiles per wave, channel groups per block): csrc/conv_split3x3.hip mpw_of / wm_of
+        mpw = 4 if cout > 128 else 2 if cout > 96 else 3 if cout > 64 else 1 if cout > 48 else 3 if cout > 32 else 2 if cout > 16 else 1
+        wm = 4 if cout > 96 else 2 if cout > 64 else 4 if cout > 48 else 1
         rpw = 4
         if wm == 4 and mpw == 1 and ROWS16 and H > 8 and not pro and not key[7]:   # 64-channel tiling without a load-side prologue: 16-row tiles,
             rpw, act1 = 8, (act1 if act1 in (0, -2) else -1)                        # bias-only / coupling epilogue compiled in, anything else at run time

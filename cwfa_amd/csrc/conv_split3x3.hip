@@ -138,8 +138,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     constexpr int XC = G::XC, EPK = G::EPK, KHB = G::KHB, XPB = G::XPB, XB = G::XB, NTAP = G::NTAP, PAD = G::PAD;
     constexpr int WN = 8 / WM, RW = G::TRW / WN, NT = 2 * RW;      // row groups, image rows and n-tiles per wave
     constexpr bool SPECIAL = G::SPECIAL;
-    static_assert(SPECIAL || (MPW == 1 && !ADD), "7x7 / 16-row tiles: the 64-channel tiling without a skip add");
-    static_assert(WM == 4 || (KS == 3 && RPW == 8 && MPW == 1 && ACT1 != EPI_COUPLE), "narrow tilings: 16-row tile, one m-tile per wave");
+    static_assert(SPECIAL || ((MPW == 1 || WM != 4) && !ADD), "7x7 / 16-row tiles: the 64-channel and narrow tilings, without a skip add");
+    static_assert(WM == 4 || (KS == 3 && RPW == 8 && MPW <= 3 && !ADD && ACT1 != EPI_COUPLE), "narrow tilings: 16-row tile, <= 3 m-tiles per wave");
+    static_assert(MPW != 3 || WM != 4, "three m-tiles per wave: the 48- / 96-channel tilings only");
     constexpr int CT = 16 * MPW * WM;                   // output channels per block
     constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     for (int mt = 0; mt < MPW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int MH = MPW < 2 ? MPW : 2;            // m-tiles whose A fragments are held at a time (register budget)
+    constexpr int MH = MPW < 2 ? MPW : MPW == 3 ? 3 : 2;   // m-tiles whose A fragments are held at a time (register budget)
     bf16x8 A[MH][3], Bq[2][3];
     float xa[NEK][8], xb[NEK][8], aa[NEK][8], ab[NEK][8];    // staged entries of the next even / odd chunk (+ skip tensor)
 
@@ -632,9 +633,13 @@ __global__ __launch_bounds__(256) void split3x3_pack_kernel(const float* __restr
     }
 }
 
-inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 64 ? 2 : 1; }
-// channel groups per block: the narrow tilings (32 / 16 output channels per block) for small banks -- packing and launch must agree
-inline int wm_of(int Cout) { return Cout > 32 ? 4 : Cout > 16 ? 2 : 1; }
+// (m-tiles per wave, channel groups per block) by bank size -- packing and launch must agree.  WM = 4: 64 / 128 / 256 channels per
+// block on 8-row tiles (64: also 16-row).  The narrow tilings (16-row tile, no load-side prologue) fit the small banks WITHOUT zero
+// rows and with more m-tiles per B fragment: 16 = (1,1); 32 = (2,1); 48 = (3,1): the 64 -> 48 output convolutions of the sub-networks
+// (on the 64-channel tiling a B fragment fed ONE m-tile and a quarter of the MFMAs ran on zero rows); 96 = (3,2): the 64 -> 96 ones
+// (a quarter of the 128-channel tiling was zero rows).
+inline int mpw_of(int Cout) { return Cout > 128 ? 4 : Cout > 96 ? 2 : Cout > 64 ? 3 : Cout > 48 ? 1 : Cout > 32 ? 3 : Cout > 16 ? 2 : 1; }
+inline int wm_of(int Cout) { return Cout > 96 ? 4 : Cout > 64 ? 2 : Cout > 48 ? 4 : 1; }
 inline int ct_of(int Cout) { return 16 * mpw_of(Cout) * wm_of(Cout); }
 inline int nsteps_of(int Cin, int ntap = 9) { return ntap * (((Cin + 15) / 16 + 1) / 2); }   // whole periods of two 16-channel chunks
 
@@ -754,6 +759,8 @@ extern "C" int cwfa_conv3x3_split_pack_f32(const float* w, void* packed, int Cou
     const dim3 grid((unsigned)((total + 255) / 256));
     uint4* out = reinterpret_cast<uint4*>(packed);
     if (ct == 32) hipLaunchKernelGGL(split3x3_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else if (ct == 48) hipLaunchKernelGGL(split3x3_pack_kernel<48>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
+    else if (ct == 96) hipLaunchKernelGGL(split3x3_pack_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     else if (ct == 16) hipLaunchKernelGGL(split3x3_pack_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     else if (mpw == 4) hipLaunchKernelGGL(split3x3_pack_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
     else if (mpw == 2) hipLaunchKernelGGL(split3x3_pack_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, nchunks, nsteps, total, 9);
@@ -796,23 +803,26 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     CWFA_REQUIRE((int64_t)p.tiles_x * ((H + TR - 1) / TR) < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_conv3x3_split_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const bool six = g_cwfa_split_products != 1;
-    if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
-    if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
     const int wm = wm_of(Cout);
-    if (wm != 4) {       // narrow tilings (<= 32 outputs): 16-row tile, no load-side prologue, NCHW / blocked input, bias / PReLU / generic epilogue
+    if (wm != 4) {       // narrow tilings (<= 48 or 65 .. 96 outputs): 16-row tile, no load-side prologue, NCHW / blocked input, bias / PReLU / generic epilogue
         CWFA_REQUIRE(!p.o.in_scale && !p.o.in_add && !p.o.out_blocked8, CWFA_E_INVAL,
-                     "cwfa_conv3x3_split_f32: banks with <= 32 outputs take no load-side prologue and write NCHW");
+                     "cwfa_conv3x3_split_f32: banks with <= 48 or 65 .. 96 outputs take no load-side prologue and write NCHW");
         const bool plain = !p.o.residual && p.o.act2 == CWFA_ACT_NONE;
         const int epi = plain && p.o.act == CWFA_ACT_NONE ? 0 : plain && p.o.act == CWFA_ACT_PRELU ? 1 : 2;
-        if (wm == 2) {
-            if (epi == 0) return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8, 2>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8, 2>(p, st);
-            if (epi == 1) return six ? launch<1, true, false, CWFA_ACT_PRELU, 3, 8, 2>(p, st) : launch<1, false, false, CWFA_ACT_PRELU, 3, 8, 2>(p, st);
-            return six ? launch<1, true, false, EPI_RUNTIME, 3, 8, 2>(p, st) : launch<1, false, false, EPI_RUNTIME, 3, 8, 2>(p, st);
-        }
-        if (epi == 0) return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8, 1>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8, 1>(p, st);
-        if (epi == 1) return six ? launch<1, true, false, CWFA_ACT_PRELU, 3, 8, 1>(p, st) : launch<1, false, false, CWFA_ACT_PRELU, 3, 8, 1>(p, st);
-        return six ? launch<1, true, false, EPI_RUNTIME, 3, 8, 1>(p, st) : launch<1, false, false, EPI_RUNTIME, 3, 8, 1>(p, st);
+#define CWFA_NARROW(M, W_)                                                                                                                   \
+    do {                                                                                                                                     \
+        if (epi == 0) return six ? launch<M, true, false, CWFA_ACT_NONE, 3, 8, W_>(p, st) : launch<M, false, false, CWFA_ACT_NONE, 3, 8, W_>(p, st);   \
+        if (epi == 1) return six ? launch<M, true, false, CWFA_ACT_PRELU, 3, 8, W_>(p, st) : launch<M, false, false, CWFA_ACT_PRELU, 3, 8, W_>(p, st); \
+        return six ? launch<M, true, false, EPI_RUNTIME, 3, 8, W_>(p, st) : launch<M, false, false, EPI_RUNTIME, 3, 8, W_>(p, st);                     \
+    } while (0)
+        if (mpw == 3 && wm == 2) CWFA_NARROW(3, 2);
+        if (mpw == 3) CWFA_NARROW(3, 1);
+        if (mpw == 2) CWFA_NARROW(2, 1);
+        CWFA_NARROW(1, 1);
+#undef CWFA_NARROW
     }
+    if (mpw == 4) return six ? launch_epi<4, true>(p, st) : launch_epi<4, false>(p, st);
+    if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
     // 64-channel tiling: 16-row tiles for the plain bias-only form (the output convolutions of the sub-networks)
     if (g_cwfa_split_rows16 && H > 8 && !p.o.in_scale && !p.o.in_add && !p.o.residual && p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE)
         return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8>(p, st);

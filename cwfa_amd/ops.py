@@ -500,7 +500,8 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
             raise ValueError("conv2d: channel-blocked input is read by the split-bf16 3x3 kernel only")
         o.in_blocked8 = 1
     if out_blocked:                         # y leaves channel-blocked: the split-bf16 3x3 kernel (bias / PReLU epilogue), or plain 1x1
-        ok3 = pc.split and pc.ks == 3 and pc.cout % 8 == 0 and residual is None and act2 is None and act in (None, "prelu")
+        ok3 = (pc.split and pc.ks == 3 and pc.cout % 8 == 0 and residual is None and act2 is None and act in (None, "prelu")
+               and not split3x3_narrow(pc.cout))
         ok1 = not pc.split and pc.ks == 1 and pc.cout >= 33 and pc.cout % 8 == 0 and not up
         if not (ok3 or ok1):                # banks with 33..64 outputs on the fp32 MFMA kernel
             raise ValueError("conv2d: channel-blocked output is written by the split-bf16 3x3 kernel (bias / PReLU) and by the "
@@ -529,7 +530,7 @@ def conv2d(x, pc, bias=None, act=None, prelu_alpha=None, residual=None, act2=Non
         check(L.cwfa_conv7x7_split_f32(_p(x), _p(pc.packed), _p(out), B, Cin, H, W, pc.cout, xbs, ybs, C.byref(o), _stream()),
               "conv7x7_split")
     elif pc.split and pc.ks == 3:
-        if pc.cout <= 32 and (in_scale is not None or in_add is not None):
+        if split3x3_narrow(pc.cout) and (in_scale is not None or in_add is not None):
             # the narrow tilings take no load-side prologue: one streaming pass materialises it (no such layer in CWFA's graphs)
             if (H * W) % 4 == 0:
                 x = plane_affine(x, in_scale, in_shift, add=in_add)
@@ -634,6 +635,12 @@ COUPLE_EPILOGUE = True       # (tuning / ablation) False: sub-networks write [s_
 def couple_fused():
     """True when the coupling epilogue is available in the active precision mode (split / bf16: the split-bf16 3x3 kernel)."""
     return COUPLE_EPILOGUE and _split_bf16 >= 2
+
+
+def split3x3_narrow(cout):
+    """Banks the split-bf16 3x3 kernel runs on its narrow tilings (16 / 32 / 48 / 96 channels per block on the 16-row tile: no zero
+    rows, more m-tiles per B fragment; csrc/conv_split3x3.hip: mpw_of / wm_of): no load-side prologue, NCHW output."""
+    return cout <= 48 or 64 < cout <= 96
 
 
 SPLIT_3X3_MIN_COUT = 1      # 3x3 banks with at least this many outputs take the split-bf16 kernel when "split_bf16" >= 2 (banks with <= 32 /
