@@ -65,13 +65,15 @@ def family(key):
         rpw = 4
         if wm == 4 and mpw == 1 and ROWS16 and H > 8 and not pro and not key[7]:   # 64-channel tiling without a load-side prologue: 16-row tiles,
             rpw, act1 = 8, (act1 if act1 in (0, -2) else -1)                        # bias-only / coupling epilogue compiled in, anything else at run time
+            if act1 != -2:
+                mpw, wm = 2, 2                                                     # two m-tiles per wave x two channel groups (not the coupling form)
         if wm != 4:
             rpw = 8
-        if wm != 4:
+        if wm != 4 and not 48 < cout <= 64:
             act1 = 0 if (plain and not act) else 2 if (plain and act == "prelu") else -1
         return "conv3x3_split_kernel<%d, %s, %s, %d, 3, %d, %d>" % (mpw, "true" if SPLIT_SIX else "false", "true" if key[7] else "false", act1, rpw, wm)
     if tag.endswith("+split") and ks == 7:
-        return "conv3x3_split_kernel<1, %s, false, 0, 7, 4, 4>" % ("true" if SPLIT_SIX else "false")
+        return "conv3x3_split_kernel<2, %s, false, 0, 7, 4, 2>" % ("true" if SPLIT_SIX else "false")
     if tag.endswith("+split"):
         return "conv%dx%d_split_kernel[%s]" % (ks, ks, tag)
     if ks == 3 and cout > 64 and WINO2D_MIN and cout >= WINO2D_MIN:

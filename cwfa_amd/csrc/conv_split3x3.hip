@@ -139,7 +139,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     constexpr int WN = 8 / WM, RW = G::TRW / WN, NT = 2 * RW;      // row groups, image rows and n-tiles per wave
     constexpr bool SPECIAL = G::SPECIAL;
     static_assert(SPECIAL || ((MPW == 1 || WM != 4) && !ADD), "7x7 / 16-row tiles: the 64-channel and narrow tilings, without a skip add");
-    static_assert(WM == 4 || (KS == 3 && RPW == 8 && MPW <= 3 && !ADD && ACT1 != EPI_COUPLE), "narrow tilings: 16-row tile, <= 3 m-tiles per wave");
+    static_assert(WM == 4 || (((KS == 3 && RPW == 8) || KS == 7) && MPW <= 3 && !ADD && ACT1 != EPI_COUPLE),
+                  "narrow tilings: 16-row tile (7x7: 8-row), <= 3 m-tiles per wave");
     static_assert(MPW != 3 || WM != 4, "three m-tiles per wave: the 48- / 96-channel tilings only");
     constexpr int CT = 16 * MPW * WM;                   // output channels per block
     constexpr int WSL = 3 * 4 * CT * 16;                // bytes of one weight slice (K = 32)
@@ -825,11 +826,13 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
     if (mpw == 2) return six ? launch_epi<2, true>(p, st) : launch_epi<2, false>(p, st);
     // 64-channel tiling: 16-row tiles for the plain bias-only form (the output convolutions of the sub-networks)
     if (g_cwfa_split_rows16 && H > 8 && !p.o.in_scale && !p.o.in_add && !p.o.residual && p.o.act == CWFA_ACT_NONE && p.o.act2 == CWFA_ACT_NONE)
-        return six ? launch<1, true, false, CWFA_ACT_NONE, 3, 8>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 3, 8>(p, st);
+        return six ? launch<2, true, false, CWFA_ACT_NONE, 3, 8, 2>(p, st) : launch<2, false, false, CWFA_ACT_NONE, 3, 8, 2>(p, st);
+    // (two m-tiles per wave x two channel groups instead of one x four: the same 64 channels per block and the same packed image, but a
+    //  B fragment feeds two m-tiles -- 30 instead of 51 ds_read_b128 per 96 MFMAs)
     // ... and for any other epilogue without a load-side prologue (activation / residual / second activation: the data-gradient and
     // unfused forward convolutions of the sub-networks in training, 64 -> 64): 160 -> ~100 us at 512 x 512
     if (g_cwfa_split_rows16 && H > 8 && !p.o.in_scale && !p.o.in_add)
-        return six ? launch<1, true, false, EPI_RUNTIME, 3, 8>(p, st) : launch<1, false, false, EPI_RUNTIME, 3, 8>(p, st);
+        return six ? launch<2, true, false, EPI_RUNTIME, 3, 8, 2>(p, st) : launch<2, false, false, EPI_RUNTIME, 3, 8, 2>(p, st);
     return six ? launch_epi<1, true>(p, st) : launch_epi<1, false>(p, st);
 }
 
@@ -871,5 +874,6 @@ extern "C" int cwfa_conv7x7_split_f32(const float* x, const void* w_packed, floa
                  "cwfa_conv7x7_split_f32: one sample's input / output must stay below 2 GiB");
     CWFA_REQUIRE((int64_t)p.tiles_x * ((H + TR - 1) / TR) < (1ll << 31) && B <= 65535, CWFA_E_SHAPE, "cwfa_conv7x7_split_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    return g_cwfa_split_products != 1 ? launch<1, true, false, CWFA_ACT_NONE, 7>(p, st) : launch<1, false, false, CWFA_ACT_NONE, 7>(p, st);
+    // (2 m-tiles per wave x 2 channel groups: a B fragment feeds two m-tiles -- 18 instead of 27 ds_read_b128 per 48 MFMAs)
+    return g_cwfa_split_products != 1 ? launch<2, true, false, CWFA_ACT_NONE, 7, 4, 2>(p, st) : launch<2, false, false, CWFA_ACT_NONE, 7, 4, 2>(p, st);
 }

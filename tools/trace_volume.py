@@ -8,7 +8,7 @@ nrows = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
 shapes = "--shapes" in sys.argv
 rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if ", 7, 4" in r["Kernel_Name"] and "conv3x3_split_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if ", 7, 4, " in r["Kernel_Name"] and "conv3x3_split_kernel" in r["Kernel_Name"]]
 segs = [rows[a:b] for a, b in zip(marks, marks[1:])]
 common = collections.Counter(len(s) for s in segs).most_common(1)[0][0]
 segs = [s for s in segs if len(s) == common]
