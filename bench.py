@@ -138,6 +138,8 @@ class ConvEvents:
 
 def conv_flops(key):
     ks, cin, cout, H, W, B = key[:6]
+    if ks == "L" and key[6].startswith("layer1x"):  # ... with the first map as a third k step: + 64 x 32
+        return 2.0 * cout * (cin * 9 + cout + cin) * H * W * B
     if ks == "L" and key[6].startswith("layer1"):   # first layer in composed form: 3x3 over the (padded) 32 input channels + the 64 x 64 1x1
         return 2.0 * cout * (cin * 9 + cout) * H * W * B
     taps = 10 if ks == "L" else ks * ks          # "L": fused 3x3 + 1x1 sub-network layer (9 + 1 taps)
@@ -148,6 +150,8 @@ def conv_bytes(key):
     """Algorithmic HBM bytes of one launch: every input tensor (x, and the skip tensor of a load-side add) read once, the
     output written once; the fused layer's residual is the x tile it already holds.  Weights are L2-resident noise."""
     ks, cin, cout, H, W, B = key[:6]
+    if ks == "L" and key[6].startswith("layer1x"):  # u (+ ones channel) is read, y is written
+        return 4.0 * (cin + cout) * H * W * B
     if ks == "L" and key[6].startswith("layer1"):   # u (+ ones channel) and the residual map x are read, y is written
         return 4.0 * (cin + 2 * cout) * H * W * B
     return 4.0 * (cin * (2 if key[7] else 1) + cout) * H * W * B
@@ -226,6 +230,8 @@ def main():
     ap.add_argument("--no-xcd-map", action="store_true", help="(ablation) plain block order in the split 3x3 kernel")
     ap.add_argument("--no-first-composed", action="store_true", help="(ablation) the first layer of every sub-network like the other two "
                     "(K = 9 x 64) instead of its composed form")
+    ap.add_argument("--no-fused-first-map", action="store_true", help="(ablation) the composed first layer reads its residual conv1x1(u) + b0 "
+                    "from a map written by a 1x1 launch instead of forming it itself")
     ap.add_argument("--no-merge-first", action="store_true", help="(ablation) every sub-network runs its own first 1x1 convolution")
     ap.add_argument("--no-merge-omega", action="store_true", help="(ablation) every condition net runs its own conv1 / downsample launches")
     ap.add_argument("--wino2d", type=int, default=None, help="(tuning) override the 2-D Winograd output-channel threshold (0 = off)")
@@ -261,6 +267,8 @@ def main():
         ops.set_option("winograd_2d", a.wino2d)
     if a.no_first_composed:
         ops.FIRST_LAYER_COMPOSED = False
+    if a.no_fused_first_map:
+        ops.FIRST_LAYER_FUSED_X = False
     if a.no_merge_first:
         from cwfa_amd import networks as _N
         _N.MERGE_FIRST_MAPS = False

@@ -119,10 +119,15 @@ __host__ __device__ constexpr int unit_off(int u) {
 // a sub-network in its composed form: conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1) with W' = W3 o [W0 | b0] over the <= 31 channels of
 // the sub-network's input u and a constant-one channel (exact with zero padding: the padded ones carry no bias), K = 9 x 32 instead
 // of 9 x 64 -- half the conv steps; the residual x = conv1x1(u) + b0 is still read from memory.
-template <bool SIX, bool INB, bool OUTB, int NPER = 2, bool TAPE = false>
+// XF (first-layer form only): the residual x = conv1x1(u) + b0 is not read either -- it is a THIRD k step of the 1x1 phase, [W1 | W0'] .
+// [h ; u | 1], with u's values at the tile's pixels loaded straight into the B-fragment layout (8 channels of a pixel per lane, L2-hot:
+// the staging just read the same tile) and W0' = [W0 | b0 | 0] as one more slice of the packed image, read from memory (12 KB,
+// cache-resident; the LDS is full): the sub-network's first 1x1 launch and its 64-channel map disappear.
+template <bool SIX, bool INB, bool OUTB, int NPER = 2, bool TAPE = false, bool XF = false>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     static_assert(!TAPE || (!INB && !OUTB && NPER == 2), "tape form: NCHW maps, full layer");
-    constexpr int NSTEP = 9 * NPER, NSLK = NSTEP + 2;     // conv steps per tile; weight slices per problem
+    static_assert(!XF || (NPER == 1 && !INB && !TAPE), "fused first map: the composed first-layer form");
+    constexpr int NSTEP = 9 * NPER, NSLK = NSTEP + 2 + (XF ? 1 : 0);     // conv steps per tile; weight slices per problem
     constexpr bool UIN = NPER == 1;                      // the 3x3 input is p.u (NCHW), not p.x
     constexpr bool INS = INB && !UIN;                    // layout of the STAGED tensor
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         {
             const int sw0 = cs, sw1 = next_slot(cs), sn0 = next_slot(sw1);         // W1 slices, next tile's slice 0
             dma_w(0, sn0, wb_next);
-            const auto rx = rsrc_of(p.x + (int64_t)tb * p.x_bs);
+            const auto rx = rsrc_of(XF ? p.y : p.x + (int64_t)tb * p.x_bs);        // (XF: unused)
+            const auto ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XF ? p.u + (int64_t)tb * p.u_bs : p.y), 0, XF ? p.u_ch * plane : 0, 0x00020000);
             const auto ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)tb * p.y_bs, 0, 64 * plane, 0x00020000);
             const auto rh = __builtin_amdgcn_make_buffer_rsrc(TAPE ? p.hid + (int64_t)tb * p.hid_bs : p.y, 0, TAPE ? 64 * plane : 0, 0x00020000);
             // offsets of this lane's (row, col) in the two layouts: NCHW: channel 4 g (+ 16 mt + r planes in the scalar offset);
@@ -370,6 +376,22 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                 if constexpr (!INB || !OUTB) oo[nt] = ok ? (unsigned)(row * p.W + col) * 4u + (unsigned)g * 4u * (unsigned)plane : OOB;
                 if constexpr (INB || OUTB) ob[nt] = ok ? (unsigned)((g >> 1) * HW + row * p.W + col) * 32u + (unsigned)(g & 1) * 16u : OOB;
             }
+            // XF: u at this lane's pixel of n-tile nt, channels 8 g .. 8 g + 7 (= k slots 8 g + j of the third k step); two sets: the
+            // next n-tile's values are requested while this one multiplies
+            unsigned uo[4];
+            float uv[2][8];
+            if constexpr (XF) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int row = row0 + 2 * wave + (nt >> 1), col = col0 + 16 * (nt & 1) + c16;
+                    uo[nt] = (col < p.W && row < p.H) ? (unsigned)(row * p.W + col) * 4u + (unsigned)(8 * g) * (unsigned)plane : OOB;
+                }
+            }
+            auto load_u = [&](int nt, float (&dst)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, uo[nt], j * plane, 0));
+            };
+            if constexpr (XF) load_u(0, uv[0]);
             f32x4 res[4];                           // residual of ONE n-tile: loaded at the end of the iteration before its epilogue
             auto load_res = [&](int nt, f32x4 (&rv)[4]) {
                 if constexpr (INB) {
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                     if (i & 1) {
                         f32x4 o4;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o4[r] = elu(acc[mt][nt][r] + rv[mt][r]);
+                        for (int r = 0; r < 4; ++r) o4[r] = elu(XF ? acc[mt][nt][r] : acc[mt][nt][r] + rv[mt][r]);
                         // (cwfa_buffer_store_b128: the store with the wait states its data registers need on gfx950, common.h)
                         cwfa_buffer_store_b128(__builtin_bit_cast(cwfa_u32x4, o4), ry, ob[nt], mt * 16 * plane);
                     }
@@ -401,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = (i & 1) * 2 + h;
-                    const float v = elu(acc[mt][nt][r] + rv[mt][r]);
+                    const float v = elu(XF ? acc[mt][nt][r] : acc[mt][nt][r] + rv[mt][r]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, oo[nt], (mt * 16 + r) * plane, 0);
                 }
             };
@@ -411,6 +433,15 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             constexpr int NA1 = 2;
             bf16x8 A1[NA1][2][3];
             auto read_a1 = [&](int i) {
+                if (XF && i >= 4) {                 // W0' fragments of m-tile pair i - 4, from the packed image's last slice in memory
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            A1[i & (NA1 - 1)][h][q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                rw, (unsigned)((g * 64 + c16) * 16 + (q * 256 + ((i - 4) * 2 + h) * 16) * 16), wb_cur + (NSTEP + 2) * WSL, 0));
+                    return;
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -433,12 +464,15 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                         split3<SIX>(hv, h1, h2, h3);
                         Hq[s][0][j] = h1; Hq[s][1][j] = h2; Hq[s][2][j] = h3;
                     }
+                if constexpr (XF) {
+                    if (nt + 1 < 4) load_u(nt + 1, uv[(nt + 1) & 1]);
+                }
                 read_a1(0);
                 FENCE();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {       // (m-tile pair, k step): 12 MFMAs on two accumulator tiles
                     const int mp = (i >> 1) * 2, s = i & 1;
-                    if (NA1 == 2 && i + 1 < 4) read_a1(i + 1);
+                    if (NA1 == 2 && i + 1 < (XF ? 6 : 4)) read_a1(i + 1);
                     if (NA1 == 1 && i > 0) read_a1(i);
                     if (s == 0) {
                         acc[mp][nt] = bias4[16 + mp * 4 + g];
@@ -454,7 +488,26 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                         FENCE();
                     }
                 }
-                load_res(nt, res);                  // consumed by this n-tile's epilogue, one iteration later
+                if constexpr (XF) {                 // third k step: + W0' . (u | 1) = the first map, never formed in memory
+                    bf16x8 Uq[3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 u1, u2 = (__bf16)0.f, u3 = (__bf16)0.f;
+                        split3<SIX>(uv[nt & 1][j], u1, u2, u3);
+                        Uq[0][j] = u1; Uq[1][j] = u2; Uq[2][j] = u3;
+                    }
+#pragma unroll
+                    for (int i = 4; i < 6; ++i) {
+                        const int mp = (i - 4) * 2;
+                        if (i + 1 < 6) read_a1(i + 1);
+                        FENCE();
+                        mfma6(acc[mp][nt], A1[i & (NA1 - 1)][0], Uq);
+                        mfma6(acc[mp + 1][nt], A1[i & (NA1 - 1)][1], Uq);
+                        FENCE();
+                    }
+                } else {
+                    load_res(nt, res);              // consumed by this n-tile's epilogue, one iteration later
+                }
                 FENCE();
             }
 #pragma unroll
@@ -485,10 +538,12 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
 //   slices 18, 19 (k step s of the 1x1): element j of group g = w1[co][16*(2s + (j>>2)) + 4g + (j&3)] -- the hidden
 //                 channel that register j & 3 of accumulator tile 2s + (j >> 2) holds in lane group g
 // (n3 = 18 slices over cin3 = 64 input channels, or the first-layer form: n3 = 9 over cin3 = 32)
+//   first-layer form, optional slice n3 + 2 (w0 != NULL): element j of group g = w0[co][8g + j], the [64][32] matrix [W0 | b0 | 0] of the
+//                 1x1 in front of the layer (third k step of the 1x1 phase: the fused first map)
 __global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w1,
-                                                               uint4* __restrict__ out, int n3, int cin3) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice n3 + 2][g 4][co 64]
-    if (i >= (n3 + 2) * 256) return;
+                                                               uint4* __restrict__ out, int n3, int cin3, const float* __restrict__ w0 = nullptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over [slice n3 + 2 (+ 1)][g 4][co 64]
+    if (i >= (n3 + 2 + (w0 ? 1 : 0)) * 256) return;
     const int co = i % 64, g = (i / 64) % 4, sl = i / 256;
     unsigned short pc[3][8];
 #pragma unroll
@@ -497,9 +552,11 @@ __global__ __launch_bounds__(256) void split_layer_pack_kernel(const float* __re
         if (sl < n3) {
             const int u = 2 * sl + (g >> 1), c = u / 9, t = u % 9;
             v = w3[((int64_t)co * cin3 + c * 16 + (g & 1) * 8 + j) * 9 + t];
-        } else {
+        } else if (sl < n3 + 2) {
             const int s = sl - n3;
             v = w1[co * 64 + 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3)];
+        } else {
+            v = w0[co * 32 + 8 * g + j];
         }
         __bf16 a1, a2, a3;
         split3<true>(v, a1, a2, a3);
@@ -533,13 +590,13 @@ extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1
     return CWFA_OK;
 }
 
-extern "C" int64_t cwfa_subnet_layer_first_packed_bytes(void) { return (int64_t)11 * WSL; }
+extern "C" int64_t cwfa_subnet_layer_first_packed_bytes(void) { return (int64_t)12 * WSL; }
 
-extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, void* packed, void* stream) {
+extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, void* packed, void* stream) {
     CWFA_REQUIRE(w3c && w1 && packed, CWFA_E_INVAL, "cwfa_subnet_layer_first_pack_f32: null pointer");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_first_pack_f32: packed image must be 16-byte aligned");
-    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((11 * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3c, w1,
-                       reinterpret_cast<uint4*>(packed), 9, 32);
+    hipLaunchKernelGGL(split_layer_pack_kernel, dim3((12 * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3c, w1,
+                       reinterpret_cast<uint4*>(packed), 9, 32, w0c);
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_first_pack_f32");
     return CWFA_OK;
 }
@@ -577,8 +634,10 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     CWFA_REQUIRE(!(layout & 2) || (y_bs & 3) == 0, CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output batch stride must be a multiple of 4");
     CWFA_REQUIRE(B >= 0 && H >= 0 && W >= 0, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: bad size");
     if (B == 0 || H == 0 || W == 0) return CWFA_OK;
-    CWFA_REQUIRE(x && packed && b3 && b1 && y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: null pointer");
-    CWFA_REQUIRE(x != y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: in-place not supported (3x3 halo)");
+    const bool fused_x = u != nullptr && x == nullptr;      // first-layer form with the first map as a third k step (packed with w0c)
+    CWFA_REQUIRE((x || fused_x) && packed && b3 && b1 && y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: null pointer");
+    CWFA_REQUIRE(x != y && u != y, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: in-place not supported (3x3 halo)");
+    if (fused_x) layout &= 2;                               // (no x: its layout bit means nothing)
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: packed image must be 16-byte aligned");
     CWFA_REQUIRE((int64_t)64 * H * W * 4 < (1ll << 31), CWFA_E_SHAPE, "cwfa_subnet_layer_split_f32: image too large for 32-bit offsets");
     LParams p{};
@@ -616,9 +675,11 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
          {&split_layer_kernel<true, false, false, 1>, &split_layer_kernel<true, true, false, 1>, &split_layer_kernel<true, false, true, 1>,
           &split_layer_kernel<true, true, true, 1>}}};
     static const kern_t tape_kerns[2] = {&split_layer_kernel<false, false, false, 2, true>, &split_layer_kernel<true, false, false, 2, true>};
-    const int first = u != nullptr ? 1 : hid != nullptr ? 2 : 0;
-    kern_t kern = first == 2 ? tape_kerns[six] : kerns[first][six][layout];
-    static bool attr_set_all[3][2][4] = {};
+    static const kern_t xf_kerns[2][2] = {{&split_layer_kernel<false, false, false, 1, false, true>, &split_layer_kernel<false, false, true, 1, false, true>},
+                                          {&split_layer_kernel<true, false, false, 1, false, true>, &split_layer_kernel<true, false, true, 1, false, true>}};
+    const int first = fused_x ? 3 : u != nullptr ? 1 : hid != nullptr ? 2 : 0;
+    kern_t kern = first == 3 ? xf_kerns[six][layout >> 1] : first == 2 ? tape_kerns[six] : kerns[first][six][layout];
+    static bool attr_set_all[4][2][4] = {};
     bool& attr_done = attr_set_all[first][six][layout];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

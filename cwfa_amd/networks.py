@@ -158,8 +158,16 @@ class wavelet_flow_subnetwork(nn.Module):
         pc_in = self._cat_bank(conv_in, u[0].shape[1]) if two else P(conv_in)
         # the first map is channel-blocked already when the 1x1 kernel that writes it can do so (see below)
         blocked = bool(split_layers and ops.BLOCKED_MAPS and not pc_in.split and pc_in.ks == 1 and pc_in.cout == 64)
+        # the first layer in its composed form (3x3 o 1x1 over the sub-network's few input channels + a ones channel: half the
+        # convolution steps) where the input is one tensor of <= 31 channels; with FIRST_LAYER_FUSED_X that launch also forms the
+        # first map conv_in(u) itself (its residual), so the 1x1 below does not run at all
+        first_form = (split_layers and ops.FIRST_LAYER_COMPOSED and not two and conv_in.kernel_size == (1, 1) and conv_in.in_channels <= 31
+                      and not pc_in.split)
+        fused_x = first_form and ops.FIRST_LAYER_FUSED_X
         pre = ops.first_map_of(self)             # computed by the plan together with the other sub-networks' (ops.first_map_scope)
-        if pre is not None and pre[0] is u and pre[1] is conv_in and blocked:
+        if fused_x:
+            b = None
+        elif pre is not None and pre[0] is u and pre[1] is conv_in and blocked:
             b = pre[2]
         elif two:
             b = ops.conv2d(u[0], pc_in, bias=conv_in.bias, out_blocked=blocked, cat=u[1])
@@ -170,16 +178,12 @@ class wavelet_flow_subnetwork(nn.Module):
         # that layout -- the next layer, and the last convolution if it runs on the split-bf16 3x3 kernel
         pc_out = None if couple is not None else P(conv_out)
         last_reads_blocked = split_layers and ops.BLOCKED_MAPS and (couple is not None or (pc_out.split and pc_out.ks == 3))
-        # the first layer in its composed form (3x3 o 1x1 over the sub-network's few input channels + a ones channel: half the
-        # convolution steps) where the input is one tensor of <= 31 channels
-        first_form = (split_layers and ops.FIRST_LAYER_COMPOSED and not two and conv_in.kernel_size == (1, 1) and conv_in.in_channels <= 31
-                      and not pc_in.split)
         for i, blk in enumerate((self.block2, self.block4, self.block6)):
             if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
                 if split_layers and i == 0 and first_form:
                     out_blocked = bool(ops.BLOCKED_MAPS)
                     b = ops.subnet_layer_first(ops.with_ones(u), b, self._first3(conv_in, blk[0], blk[2]), blk[0].bias, blk[2].bias,
-                                               layout=int(blocked) | (int(out_blocked) << 1))
+                                               layout=(0 if fused_x else int(blocked)) | (int(out_blocked) << 1))
                     blocked = out_blocked
                     continue
                 if split_layers:                                        # both convs on the bf16 matrix pipe
@@ -228,6 +232,10 @@ class wavelet_flow_subnetwork(nn.Module):
         u = parts[0] if len(parts) == 1 else list(parts)
         self._stack(u, self.block12, self.block72[1], couple=(x, out, clamp_kind, clamp, pre_scale, rev, logdet))
         return True
+
+    def fused_layers(self):
+        """The three residual layers run on the fused layer kernel (64 channels, biases present)."""
+        return self.n_ch == 64 and all(blk[0].bias is not None and blk[2].bias is not None for blk in (self.block2, self.block4, self.block6))
 
     def first_conv_of(self, parts):
         """(input tensor, 1x1 module) of this sub-network's first convolution for the condition list ``parts`` if that is ONE tensor
@@ -326,6 +334,8 @@ def merged_first_maps(jobs):
     groups = {}
     for net, parts in jobs:
         fc = net.first_conv_of(parts) if hasattr(net, "first_conv_of") else None
+        if fc is not None and ops.FIRST_LAYER_COMPOSED and ops.FIRST_LAYER_FUSED_X and fc[1].in_channels <= 31 and net.fused_layers():
+            continue                             # that sub-network's first layer forms its first map itself (subnet_layer_first, x = None)
         if fc is not None:
             groups.setdefault(id(fc[0]), []).append((net, fc[0], fc[1]))
     out = {}

@@ -678,6 +678,7 @@ def pack_split_layer_weight(w3, w1):
 
 
 FIRST_LAYER_COMPOSED = True   # (tuning / ablation) False: the first layer of a sub-network runs like the other two (K = 9 x 64)
+FIRST_LAYER_FUSED_X = True      # ... and its residual conv1x1(u) + b0 formed inside that launch (no first 1x1 launch, no first map in memory)
 
 
 def pack_first_layer_weight(w0, b0, w3, w1):
@@ -693,8 +694,10 @@ def pack_first_layer_weight(w0, b0, w3, w1):
     wc = torch.einsum("omt,mi->oit", w3.double().reshape(64, 64, 9), w0p)
     w3c = torch.zeros((64, 32, 3, 3), dtype=torch.float32, device=w0.device)
     w3c[:, :cin + 1] = wc.reshape(64, cin + 1, 3, 3).to(torch.float32)
+    w0c = torch.zeros((64, 32), dtype=torch.float32, device=w0.device)          # [W0 | b0 | 0]: the first map as a third k step of the 1x1 phase
+    w0c[:, :cin + 1] = w0p.to(torch.float32)
     packed = torch.empty(L.cwfa_subnet_layer_first_packed_bytes(), dtype=torch.uint8, device=w0.device)
-    check(L.cwfa_subnet_layer_first_pack_f32(_p(w3c), _p(w1), _p(packed), _stream()), "subnet_layer_first_pack")
+    check(L.cwfa_subnet_layer_first_pack_f32(_p(w3c), _p(w1), _p(w0c), _p(packed), _stream()), "subnet_layer_first_pack")
     pc = PackedConv(packed, 64, cin + 1, 3, False, w3._version, w3.data_ptr(), split=True)
     pc.version1, pc.src_ptr1 = w1._version, w1.data_ptr()
     return pc
@@ -703,17 +706,21 @@ def pack_first_layer_weight(w0, b0, w3, w1):
 def subnet_layer_first(u1, x, pc, b3, b1, layout=0):
     """y = ELU(conv1x1(ELU(conv3x3'(u1) + b3)) + b1 + x): the first layer of a sub-network with its 3x3 composed with the 1x1 in
     front (pack_first_layer_weight).  ``u1``: the sub-network's input plus a constant-one channel [B, cin + 1 <= 32, H, W];
-    ``x`` = conv1x1(u) + b0, the residual ([B,64,H,W]; ``layout`` bits as in subnet_layer)."""
+    ``x`` = conv1x1(u) + b0, the residual ([B,64,H,W]; ``layout`` bits as in subnet_layer), or None: the kernel then forms it itself
+    as a third k step of its 1x1 phase (the first 1x1 launch of the sub-network and its map are never needed)."""
     L = _lib.lib()
     u1, ubs = planes(u1, "u1")
-    x, xbs = planes(x, "x")
     B, Cu, H, W = u1.shape
-    if tuple(x.shape) != (B, 64, H, W) or Cu != pc.cin:
-        raise ValueError(f"subnet_layer_first: u1 {tuple(u1.shape)} / x {tuple(x.shape)} do not match the composed bank ({pc.cin} inputs)")
-    out = torch.empty((B, 64, H, W), dtype=torch.float32, device=x.device)
+    xbs = 0
+    if x is not None:                       # (None: the kernel forms the first map itself from u1 and the packed [W0 | b0]: FIRST_LAYER_FUSED_X)
+        x, xbs = planes(x, "x")
+    if (x is not None and tuple(x.shape) != (B, 64, H, W)) or Cu != pc.cin:
+        raise ValueError(f"subnet_layer_first: u1 {tuple(u1.shape)} / x {None if x is None else tuple(x.shape)} do not match the composed "
+                         f"bank ({pc.cin} inputs)")
+    out = torch.empty((B, 64, H, W), dtype=torch.float32, device=u1.device)
     rec = conv_event_sink
     if rec is not None:
-        key = ("L", 32, 64, H, W, B, "layer1+split", False)
+        key = ("L", 32, 64, H, W, B, "layer1+split" if x is not None else "layer1x+split", False)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -369,9 +369,12 @@ int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float*
  * W' = W3 o [W0 | b0] over u's channels and a constant-one channel (exact under zero padding: padded ones carry no bias): K = 9 x 32
  * instead of 9 x 64 -- half the convolution steps of the layer.  u: [B, u_ch <= 32, H, W] NCHW INCLUDING the ones channel;
  * x = conv1x1(u) + b0 (the residual, layout bit 0); packed = cwfa_subnet_layer_first_pack_f32(w3c [64,32,3,3] the composed bank,
- * zero in unused input channels; w1 [64,64,1,1]): cwfa_subnet_layer_first_packed_bytes() bytes. */
+ * zero in unused input channels; w1 [64,64,1,1]; w0c nullable): cwfa_subnet_layer_first_packed_bytes() bytes.
+ * With w0c = [W0 | b0 | 0] ([64,32], the 1x1 bank over u's channels and the ones channel) in the packed image and x == NULL the
+ * residual is not read either: the layer's 1x1 phase takes it as a third k step, [W1 | W0c] . [h ; u], from u's values at the tile's
+ * pixels -- the sub-network's first 1x1 launch and its 64-channel map never exist. */
 int64_t cwfa_subnet_layer_first_packed_bytes(void);
-int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, void* packed, void* stream);
+int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, void* packed, void* stream);
 int cwfa_subnet_layer_first_f32(const float* u, const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                 int u_ch, int H, int W, int64_t u_bs, int64_t x_bs, int64_t y_bs, int layout, void* stream);
 /* Tape form (training forward, SURVEY.md 8f row 1 / CWFA.py:966-1006): the same launch also writes the hidden map

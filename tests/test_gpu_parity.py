@@ -1614,6 +1614,11 @@ def test_first_layer_composed_form_is_fp32_accurate(cfg):
         assert_close(y, ref, 5e-6, "composed first layer")
         yb = ops.subnet_layer_first(u1, _to_blocked(x), pc, b3.cuda(), b1.cuda(), layout=3)
         assert torch.equal(_from_blocked(yb), y)
+        # x = None: the launch forms the first map itself (third k step of its 1x1 phase from u1 and the packed [W0 | b0])
+        yx = ops.subnet_layer_first(u1, None, pc, b3.cuda(), b1.cuda())
+        assert_close(yx, ref, 5e-6, "composed first layer, fused first map")
+        yxb = ops.subnet_layer_first(u1, None, pc, b3.cuda(), b1.cuda(), layout=2)
+        assert torch.equal(_from_blocked(yxb), yx)
         # the plain layer on the same maps: the same function up to the rounding of x between the two convolutions
         y2 = ops.subnet_layer(x, ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda())
         assert_close(y2, y, 5e-6, "composed vs two-step")
@@ -1625,12 +1630,16 @@ def test_first_layer_composed_form_is_fp32_accurate(cfg):
             net = N.wavelet_flow_subnetwork2D(cin, 2 * cin).cuda()
             with torch.no_grad():
                 a1 = net(u.cuda())
+                ops.FIRST_LAYER_FUSED_X = False
+                a2 = net(u.cuda())
                 ops.FIRST_LAYER_COMPOSED = False
                 a0 = net(u.cuda())
-            assert not torch.equal(a0, a1)
+            assert not torch.equal(a0, a1) and not torch.equal(a2, a1)
             assert_close(a1, a0, 5e-6, "sub-network with / without the composed first layer")
+            assert_close(a2, a0, 5e-6, "sub-network with the composed first layer reading its first map")
     finally:
         ops.FIRST_LAYER_COMPOSED = True
+        ops.FIRST_LAYER_FUSED_X = True
         ops.set_precision("fp32")
 
 
@@ -1650,6 +1659,7 @@ def test_cat_step_with_merged_first_maps_equals_the_separate_launches():
     calls = []
     real = N.merged_first_maps
     ops.set_precision("split_bf16")
+    ops.FIRST_LAYER_FUSED_X = False        # (with it the first layers form their first maps themselves and nothing is left to merge: below)
     try:
         outs = []
         for flag in (True, False):
@@ -1662,9 +1672,20 @@ def test_cat_step_with_merged_first_maps_equals_the_separate_launches():
         assert calls == [5, 5, 0, 0], calls                    # all five sub-networks merged when on, none when off
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+        # the default: every first layer takes its first map as a third k step of its own 1x1 phase -- no first 1x1 launch at all
+        ops.FIRST_LAYER_FUSED_X = True
+        N.MERGE_FIRST_MAPS = True
+        del calls[:]
+        with torch.no_grad():
+            (z, lo), j = gi(x, c=c)
+            xi, _ = gi([None, low], c=c, rev=True)
+        assert calls == [0, 0], calls
+        for a, b in zip((z, lo, j, xi), outs[0]):
+            assert_close(a, b, 1e-5, "fused first maps vs first maps from memory")
     finally:
         N.merged_first_maps = real
         N.MERGE_FIRST_MAPS = True
+        ops.FIRST_LAYER_FUSED_X = True
         ops.set_precision("fp32")
 
 
