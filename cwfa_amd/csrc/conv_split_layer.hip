@@ -89,9 +89,10 @@ __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// ELU = median(v, exp(v) - 1, 0): for v > 0, exp(v) - 1 > v > 0; for v < 0, v <= exp(v) - 1 < 0 -- one v_med3_f32 instead of a
+// compare and a select (the 1x1 phase of the layer is bound by exactly these instructions: 192 ELUs per lane and tile)
 __device__ __forceinline__ float elu(float v) {
-    const float e = __expf(v) - 1.0f;
-    return v > 0.f ? v : e;
+    return __builtin_amdgcn_fmed3f(v, __expf(v) - 1.0f, 0.f);
 }
 
 // v = a1 + a2 + a3 exactly (each difference is exact: the subtrahend is the minuend rounded to 8 significant bits)
