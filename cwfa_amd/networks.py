@@ -153,6 +153,14 @@ class wavelet_flow_subnetwork(nn.Module):
         # ``u`` may be the list [half, condition] of a coupling block's input: the 1x1 then reads cat(half, condition) from the
         # two tensors (ops.pack_conv_weight_cat) instead of a materialised concatenation (coupling_layers.py:74-87)
         two = isinstance(u, (list, tuple))
+        u1 = None
+        if (two and split_layers and ops.FIRST_LAYER_COMPOSED and ops.FIRST_LAYER_FUSED_X and conv_in.kernel_size == (1, 1)
+                and conv_in.in_channels <= 31 and sum(t.shape[1] for t in u) == conv_in.in_channels):
+            # few input channels (the coarse steps' GLOW / AllInOne blocks): the composed first layer with its fused first map takes
+            # cat(half, condition, 1) as ONE small tensor -- no 1x1 launch, half the convolution steps
+            B_ = u[0].shape[0]
+            u1 = ops.concat_channels(list(u) + [torch.ones((B_, 1, H_, W_), dtype=torch.float32, device=u[0].device)])
+            u, two = u1[:, :-1], False
         if two and not (len(u) == 2 and ops.VIRTUAL_CAT and conv_in.kernel_size == (1, 1) and conv_in.out_channels <= 64):
             u, two = ops.concat_channels(list(u)), False
         pc_in = self._cat_bank(conv_in, u[0].shape[1]) if two else P(conv_in)
@@ -182,7 +190,7 @@ class wavelet_flow_subnetwork(nn.Module):
             if fused:       # 3x3 -> ELU -> 1x1 -> +b -> ELU in one launch, hidden map stays in registers
                 if split_layers and i == 0 and first_form:
                     out_blocked = bool(ops.BLOCKED_MAPS)
-                    b = ops.subnet_layer_first(ops.with_ones(u), b, self._first3(conv_in, blk[0], blk[2]), blk[0].bias, blk[2].bias,
+                    b = ops.subnet_layer_first(u1 if u1 is not None else ops.with_ones(u), b, self._first3(conv_in, blk[0], blk[2]), blk[0].bias, blk[2].bias,
                                                layout=(0 if fused_x else int(blocked)) | (int(out_blocked) << 1))
                     blocked = out_blocked
                     continue

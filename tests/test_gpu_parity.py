@@ -1689,6 +1689,42 @@ def test_cat_step_with_merged_first_maps_equals_the_separate_launches():
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("block_type", ["GLOW", "AI1", "RNVP"])
+def test_data_dependent_blocks_with_the_fused_first_layer(block_type):
+    """Coupling blocks whose sub-network input cat(half, condition) has <= 31 channels (the coarse steps): the composed first layer
+    with its fused first map takes cat(half, condition, 1) as one small tensor.  Against the same graph with the form switched off
+    (two-source 1x1 + full first layer), both directions, split precision; and the form must really be taken."""
+    from cwfa_amd import CWFA, ops
+    torch.manual_seed(31)
+    np.random.seed(31)
+    conv_inn, _ = CWFA.build_networks(16, 48, 2, block_type=block_type, with_lrnn=False, cond_chans=4, device="cuda")
+    gi = conv_inn[0]
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 16, 48, 48, generator=g).cuda()
+    c = [torch.randn(2, 8, 48, 48, generator=g).cuda(), 0.1 * torch.randn(2, 8, 48, 48, generator=g).cuda()]
+    z0 = torch.randn(2, 8, 48, 48, generator=g).cuda()
+    low = torch.randn(2, 8, 48, 48, generator=g).cuda()
+    seen = []
+    real = ops.subnet_layer_first
+    ops.set_precision("split_bf16")
+    try:
+        outs = []
+        for flag in (True, False):
+            ops.FIRST_LAYER_FUSED_X = flag
+            ops.subnet_layer_first = lambda u1, xx, *a, **k: (seen.append((flag, xx is None, u1.shape[1])), real(u1, xx, *a, **k))[1]
+            with torch.no_grad():
+                (z, lo), j = gi(x, c=c)
+                xi, ji = gi([z0, low], c=c, rev=True)
+            outs.append((z, lo, j, xi, ji))
+        assert any(f and fused and ch > 9 for f, fused, ch in seen), seen      # a two-tensor input went through the fused form
+        for a, b in zip(*outs):
+            assert_close(a, b, 2e-5, f"{block_type}: fused first layer vs the two-source 1x1")
+    finally:
+        ops.subnet_layer_first = real
+        ops.FIRST_LAYER_FUSED_X = True
+        ops.set_precision("fp32")
+
+
 def test_split_bf16_subnetwork_matches_the_fp32_path():
     """A whole coupling sub-network (networks.py:586-671) with the opt-in split level 2 -- its three fused layers on
     split_layer_kernel -- against the default fp32 path on the same input, at a size with ragged 32x32 tiles."""
