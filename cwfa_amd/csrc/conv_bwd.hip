@@ -456,7 +456,8 @@ __device__ __forceinline__ void wsplit3(float v, __bf16& a1, __bf16& a2, __bf16&
     }
 }
 
-template <bool SIX>
+// KS = 3, or 1: the 1x1 weight gradient as the same walk with one tap (one dy copy, one x row in use)
+template <bool SIX, int KS = 3>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
     using namespace ws;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -467,15 +468,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
     const int HW = p.H * p.W;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int NQ = SIX ? 3 : 1;
+    constexpr int NQ = SIX ? 3 : 1, PAD = KS / 2, TAPS = KS * KS;
     const bool is_dy = wave < 4;                              // (uniform) staging role
     const int ch = (tid & 255) >> 2, grp = tid & 3;           // channel of the tile, group of eight pixels
 
-    f32x4 acc[2][9];
+    f32x4 acc[2][TAPS];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TAPS; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
     for (int unit = blockIdx.x; unit < p.nstrips; unit += gridDim.x) {
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
                 e[1 + j] = lo[j];
                 e[5 + j] = hi[j];
             }
-            if (is_dy) {
+            if (is_dy && KS > 1) {
                 e[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rowok && px >= 1 && px - 1 < p.W) ? base - 4 : OOB, 0, 0));
                 e[9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rowok && px + 8 < p.W) ? base + 32 : OOB, 0, 0));
             }
@@ -508,19 +509,19 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
             if (is_dy) {
                 __bf16 pc[3][10];
 #pragma unroll
-                for (int i = 0; i < 10; ++i) wsplit3<SIX>(e[i], pc[0][i], pc[1][i], pc[2][i]);
+                for (int i = (KS > 1 ? 0 : 1); i < (KS > 1 ? 10 : 9); ++i) wsplit3<SIX>(e[i], pc[0][i], pc[1][i], pc[2][i]);
                 if (count) {
 #pragma unroll
                     for (int i = 1; i <= 8; ++i) bsum += e[i];
                 }
                 char* dst = lds + buf * DYBUF + ch * DYROW + grp * 16;
 #pragma unroll
-                for (int s = 0; s < 3; ++s)                   // copy s (= kx): element k <-> dy[px0 + k + 1 - s]
+                for (int s = 0; s < KS; ++s)                  // copy s (= kx): element k <-> dy[px0 + k + PAD - s]
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         bf16x8 v;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = pc[q][j + 2 - s];
+                        for (int j = 0; j < 8; ++j) v[j] = pc[q][j + 1 + PAD - s];
                         *reinterpret_cast<bf16x8*>(dst + (s * 3 + q) * DYPLANE) = v;
                     }
             } else {
@@ -537,33 +538,32 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
                 }
             }
         };
-        // ---- fill: x rows y0 - 1, y0, y0 + 1 -> slots 0, 1, 2; dy row y0 -> buffer 0
+        // ---- fill: x rows y0 - PAD .. y0 + PAD -> slots 0 .. KS - 1; dy row y0 -> buffer 0
         __syncthreads();                                       // (the previous unit's last reads)
         if (is_dy) {
             load_row(y0);
             store_row(0, 0, true);
         } else {
-            load_row(y0 - 1);
-            store_row(0, 0, false);
-            load_row(y0);
-            store_row(1, 0, false);
-            load_row(y0 + 1);
-            store_row(2, 0, false);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                load_row(y0 - PAD + i);
+                store_row(i, 0, false);
+            }
         }
         __syncthreads();
         for (int y = y0; y < y1; ++y) {
             const int j = y - y0;
-            // next step's rows: dy row y + 1 -> buffer (j + 1) & 1, x row y + 2 -> slot (j + 3) & 3 (free: last read at step y - 1)
-            load_row(is_dy ? y + 1 : y + 2);
+            // next step's rows: dy row y + 1 -> buffer (j + 1) & 1, x row y + PAD + 1 -> slot (j + KS) & 3 (free: last read at step y - 1)
+            load_row(is_dy ? y + 1 : y + PAD + 1);
             const char* dyb = lds + (j & 1) * DYBUF + (mt * 16 + c16) * DYROW + g * 16;
             const char* xb = lds + 2 * DYBUF + ((nh * 2) * 16 + c16) * XROW + g * 16;
-            bf16x8 A[3][3];
+            bf16x8 A[KS][3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) A[s][q] = *reinterpret_cast<const bf16x8*>(dyb + (s * 3 + q) * DYPLANE);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < KS; ++ky) {
                 const int slot = (j + ky) & 3;
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
@@ -571,8 +571,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) Bq[q] = *reinterpret_cast<const bf16x8*>(xb + q * XPLANE + n * 16 * XROW + slot * 64);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        f32x4 c = acc[n][ky * 3 + kx];
+                    for (int kx = 0; kx < KS; ++kx) {
+                        f32x4 c = acc[n][ky * KS + kx];
                         if constexpr (SIX) {
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][2], Bq[0], c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][1], Bq[1], c, 0, 0, 0);
@@ -581,11 +581,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][0], Bq[1], c, 0, 0, 0);
                         }
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kx][0], Bq[0], c, 0, 0, 0);
-                        acc[n][ky * 3 + kx] = c;
+                        acc[n][ky * KS + kx] = c;
                     }
                 }
             }
-            store_row((j + 3) & 3, (j + 1) & 1, y + 1 < y1);
+            store_row((j + KS) & 3, (j + 1) & 1, y + 1 < y1);
             __syncthreads();
         }
     }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
         if (is_dy && grp == 0 && co0 + ch < p.Cout) p.bpart[(int64_t)blockIdx.x * p.Cout + co0 + ch] = t;
     }
     // accumulator register r of tile (n, tap): co = co0 + 16 mt + 4 g + r, ci = ci0 + 16 (2 nh + n) + c16
-    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.Cin * 9;
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.Cin * TAPS;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int ci = ci0 + (nh * 2 + n) * 16 + c16;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_split_kernel(WgParams p) {
             const int co = co0 + mt * 16 + 4 * g + r;
             if (co < p.Cout) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) out[((int64_t)co * p.Cin + ci) * 9 + t] = acc[n][t][r];
+                for (int t = 0; t < TAPS; ++t) out[((int64_t)co * p.Cin + ci) * TAPS + t] = acc[n][t][r];
             }
         }
     }
@@ -710,21 +710,27 @@ extern "C" int cwfa_conv2d_wgrad_f32(const float* x, const float* dy, float* dw,
     p.bpart = db ? p.part + (int64_t)workers * n : nullptr;
     dim3 grid(workers, (Cout + 63) / 64, (Cin + 63) / 64);
     static bool attr1 = false, attr3 = false;
-    if (ks == 3 && g_cwfa_wgrad_split && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) && cwfa_aligned16(dy) &&
+    // (1x1: only banks of one 64 x 64 tile -- the sub-networks' -- where a block stages each operand once: 60 -> 52 us at 512 x 512; with
+    //  several tiles every block re-splits its operands for 12 MFMAs per step and the fp32 form is faster, 444 vs 628 us at 256 -> 256)
+    if ((ks == 3 || (ks == 1 && Cout <= 64 && Cin <= 64)) && g_cwfa_wgrad_split && W % 4 == 0 && x_bs % 4 == 0 && dy_bs % 4 == 0 && cwfa_aligned16(x) && cwfa_aligned16(dy) &&
         (int64_t)H * W % 4 == 0) {
         // units = (sample, 32-pixel column, segment of ws::SEG rows); the same workers and partial banks as the fp32 forms
         p.sx = (W + 31) / 32;
         p.sy = (H + ws::SEG - 1) / ws::SEG;
         p.nstrips = B * p.sy * p.sx;
         const bool six = g_cwfa_split_products != 1;
-        auto kern = six ? &conv_wgrad_split_kernel<true> : &conv_wgrad_split_kernel<false>;
-        static bool attr_s[2] = {false, false};
-        if (!attr_s[six]) {
+        auto kern = ks == 3 ? (six ? &conv_wgrad_split_kernel<true, 3> : &conv_wgrad_split_kernel<false, 3>)
+                            : (six ? &conv_wgrad_split_kernel<true, 1> : &conv_wgrad_split_kernel<false, 1>);
+        static bool attr_s4[4] = {false, false, false, false};
+        bool& attr_ok = attr_s4[(ks == 1 ? 2 : 0) + (six ? 1 : 0)];
+        if (!attr_ok) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ws::LDS_BYTES);
             CWFA_REQUIRE(e == hipSuccess, CWFA_E_HIP, "cwfa_conv2d_wgrad_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_s[six] = true;
+            attr_ok = true;
         }
-        dim3 sgrid(min(workers, p.nstrips), grid.y, grid.z);
+        // (one block per CU: 144 KB of LDS; the fp32 1x1 form asks for two per CU)
+        const int tiles = (int)(grid.y * grid.z);
+        dim3 sgrid(min(min(workers, max(1, (256 + tiles - 1) / tiles)), p.nstrips), grid.y, grid.z);
         hipLaunchKernelGGL(kern, sgrid, dim3(512), ws::LDS_BYTES, st, p);
         CWFA_LAUNCH_CHECK("cwfa_conv2d_wgrad_f32");
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw, n, (int)sgrid.x, beta);

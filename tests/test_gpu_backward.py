@@ -51,11 +51,12 @@ def test_conv_weight_gradient_vs_autograd(cfg):
     assert torch.equal(got, ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks))
 
 
+@pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("cfg", [  # (B, Cin, Cout, H, W): W % 4 == 0 (else the fp32 form runs)
     (1, 64, 64, 64, 64), (2, 64, 64, 37, 44), (1, 70, 130, 19, 36), (1, 8, 8, 6, 4), (1, 64, 64, 5, 100), (3, 29, 48, 16, 32),
     (1, 64, 64, 33, 32), (1, 128, 64, 70, 96), (2, 16, 96, 65, 8)])
-def test_conv_weight_gradient_split_form_vs_autograd(cfg):
-    """The 3x3 weight gradient on the bf16 matrix cores in split arithmetic (option "wgrad_split", what set_precision("split_bf16")
+def test_conv_weight_gradient_split_form_vs_autograd(cfg, ks):
+    """The 3x3 / 1x1 weight gradient on the bf16 matrix cores in split arithmetic (option "wgrad_split", what set_precision("split_bf16")
     selects): same float64 reference and bound as the fp32 forms -- segment borders (SEG = 32 rows), ragged right edges, partial
     channel tiles, several samples, accumulation into an existing buffer, strided operands, determinism."""
     from cwfa_amd import ops
@@ -63,19 +64,19 @@ def test_conv_weight_gradient_split_form_vs_autograd(cfg):
     g = torch.Generator().manual_seed(sum(cfg) + 5)
     x = torch.randn(B, Cin, H, W, generator=g)
     dy = torch.randn(B, Cout, H, W, generator=g)
-    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
-    (F.conv2d(x.double(), w, padding=1) * dy.double()).sum().backward()
+    w = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, padding=ks // 2) * dy.double()).sum().backward()
     ops.set_option("wgrad_split", 1)
     try:
-        got, gb = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3, want_bias=True)
-        base = torch.randn(Cout, Cin, 3, 3, generator=g)
+        got, gb = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks, want_bias=True)
+        base = torch.randn(Cout, Cin, ks, ks, generator=g)
         xb = torch.randn(B, Cin + 3, H, W, generator=g)
         xb[:, 2:2 + Cin] = x
         bb = torch.randn(Cout, generator=g)
-        acc, accb = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), 3, out=base.cuda().clone(), accumulate=True, bias_out=bb.cuda().clone())
-        again = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3)
+        acc, accb = ops.conv2d_wgrad(xb.cuda()[:, 2:2 + Cin], dy.cuda(), ks, out=base.cuda().clone(), accumulate=True, bias_out=bb.cuda().clone())
+        again = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks)
         ops.set_option("wgrad_split", 0)
-        fp32 = ops.conv2d_wgrad(x.cuda(), dy.cuda(), 3)
+        fp32 = ops.conv2d_wgrad(x.cuda(), dy.cuda(), ks)
     finally:
         ops.set_option("wgrad_split", 0)
     assert_close(got, w.grad, 3e-6, f"dW {cfg}")
