@@ -17,6 +17,7 @@ to autograd as the gradients of the Function's parameter inputs, so ``.grad`` ac
 ``torch.optim`` optimiser work unchanged.  Double backward is not supported (the tapes are released by the backward pass).
 """
 import math
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -89,7 +90,7 @@ class _SubnetFn(Function):
     def forward(ctx, net, conv_in, conv_out, u, *params):
         from . import training
         a, tape = training.subnet_forward_train(net, u, conv_in, conv_out)
-        ctx.tape, ctx.params = tape, params
+        ctx.tape, ctx.params, ctx.net = tape, params, net
         ctx.set_materialize_grads(False)
         return a
 
@@ -97,6 +98,7 @@ class _SubnetFn(Function):
     def backward(ctx, g):
         from . import training
         n = len(ctx.params)
+        _forget(ctx.net)                         # the node's tape is spent: a later call must build a new node
         if g is None:
             return (None,) * (4 + n)
         with _capture(ctx.params) as cap:
@@ -105,11 +107,37 @@ class _SubnetFn(Function):
         return (None, None, None, gu, *cap.grads)
 
 
+REUSE_SUBNET_NODES = True     # see subnet()
+
+
+def _forget(net):
+    if getattr(net, "_cwfa_ag_memo", None) is not None:
+        object.__setattr__(net, "_cwfa_ag_memo", None)
+
+
 def subnet(net, u, conv_in, conv_out):
-    """``wavelet_flow_subnetwork._stack`` (networks.py:641-667) as one autograd node: 1x1 -> 3 residual layers -> 3x3."""
+    """``wavelet_flow_subnetwork._stack`` (networks.py:641-667) as one autograd node: 1x1 -> 3 residual layers -> 3x3.
+
+    The reference's training step evaluates every sub-network of a conditional-affine step TWICE on the same tensors -- in the
+    inverse pass of the reconstruction term (CWFA.py:911) and in the forward pass of the NLL term (CWFA.py:966) -- and lets
+    autograd add the two gradient contributions.  A sub-network is a deterministic function of (input, parameters), so the second
+    call returns the FIRST call's output tensor: one forward, and -- the node being shared -- one backward with the summed gradient.
+    The memo lives on the module, is keyed by the input tensor object / version and every parameter's version, holds its tensors
+    weakly and is dropped as soon as the node's backward has run."""
     convs = [conv_in, net.block2[0], net.block2[2], net.block4[0], net.block4[2], net.block6[0], net.block6[2], conv_out]
     params = _params_of([c.weight for c in convs] + [c.bias for c in convs])
-    return _SubnetFn.apply(net, conv_in, conv_out, u, *params)
+    key = None
+    if REUSE_SUBNET_NODES:
+        key = (id(u), u._version, id(conv_in), id(conv_out), ops.pack_epoch(), ops._split_bf16) + tuple((id(p), p._version) for p in params)
+        hit = getattr(net, "_cwfa_ag_memo", None)
+        if hit is not None and hit[0] == key:
+            out, src = hit[1](), hit[2]()
+            if out is not None and src is u:
+                return out
+    out = _SubnetFn.apply(net, conv_in, conv_out, u, *params)
+    if key is not None:
+        object.__setattr__(net, "_cwfa_ag_memo", (key, weakref.ref(out), weakref.ref(u)))
+    return out
 
 
 class _CondFn(Function):
@@ -331,10 +359,28 @@ class _ConcatFn(Function):
         return tuple(out)
 
 
+_concat_memo = []             # [(key, weakrefs of the parts, weakref of the result)], a handful of entries
+
+
 def concat(parts):
-    """torch.cat(parts, 1) through the strided plane-copy kernel, as an autograd node."""
+    """torch.cat(parts, 1) through the strided plane-copy kernel, as an autograd node.  The same tensor OBJECTS (same versions)
+    concatenated again give the same result tensor while it is alive, so that sub-network nodes fed by it can be reused
+    (``subnet``): the condition list of a step is concatenated once for the inverse and the forward pass."""
     parts = list(parts)
-    return parts[0] if len(parts) == 1 else _ConcatFn.apply(*parts)
+    if len(parts) == 1:
+        return parts[0]
+    key = tuple((id(t), t._version) for t in parts)
+    if REUSE_SUBNET_NODES:
+        for k, refs, res in _concat_memo:
+            if k == key:
+                out = res()
+                if out is not None and all(r() is t for r, t in zip(refs, parts)):
+                    return out
+    out = _ConcatFn.apply(*parts)
+    if REUSE_SUBNET_NODES:
+        _concat_memo.append((key, [weakref.ref(t) for t in parts], weakref.ref(out)))
+        del _concat_memo[:-8]
+    return out
 
 
 class _Haar1dFn(Function):
