@@ -507,6 +507,10 @@ class _MixedStepPlan(_CatStepPlan):
         return v
 
     def run(self, x_or_z, c, rev, sumsq=None, jac=True):
+        with ops.ones_channel_scope():       # (condition | 1) of the composed first layers: built once per condition tensor and step
+            return self._run(x_or_z, c, rev, sumsq, jac)
+
+    def _run(self, x_or_z, c, rev, sumsq, jac):
         g = self.graph
         cond_of = dict(zip(g.condition_nodes, c))
         first = next(t for t in x_or_z if t is not None)

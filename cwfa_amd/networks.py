@@ -158,8 +158,8 @@ class wavelet_flow_subnetwork(nn.Module):
                 and conv_in.in_channels <= 31 and sum(t.shape[1] for t in u) == conv_in.in_channels):
             # few input channels (the coarse steps' GLOW / AllInOne blocks): the composed first layer with its fused first map takes
             # cat(half, condition, 1) as ONE small tensor -- no 1x1 launch, half the convolution steps
-            B_ = u[0].shape[0]
-            u1 = ops.concat_channels(list(u) + [torch.ones((B_, 1, H_, W_), dtype=torch.float32, device=u[0].device)])
+            # (the LAST tensor is the condition, the same for every block of the step: its (condition | 1) is built once per step)
+            u1 = ops.concat_channels(list(u[:-1]) + [ops.with_ones(u[-1])])
             u, two = u1[:, :-1], False
         if two and not (len(u) == 2 and ops.VIRTUAL_CAT and conv_in.kernel_size == (1, 1) and conv_in.out_channels <= 64):
             u, two = ops.concat_channels(list(u)), False

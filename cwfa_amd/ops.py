@@ -774,12 +774,26 @@ class ones_channel_scope:
         return False
 
 
+_ones_planes = {}
+
+
+def ones_plane(B, H, W, device):
+    """A constant [B,1,H,W] tensor of ones (read-only: the ones channel of the composed first layers), built once per shape."""
+    key = (B, H, W, str(device))
+    hit = _ones_planes.get(key)
+    if hit is None:
+        if len(_ones_planes) > 8:
+            _ones_planes.clear()
+        hit = _ones_planes[key] = torch.ones((B, 1, H, W), dtype=torch.float32, device=device)
+    return hit
+
+
 def with_ones(t):
     hit = _ones_scope.get(id(t)) if _ones_scope is not None else None
     if hit is not None and hit[0] is t:
         return hit[1]
     B, _, H, W = t.shape
-    u1 = concat_channels([t, torch.ones((B, 1, H, W), dtype=torch.float32, device=t.device)])
+    u1 = concat_channels([t, ones_plane(B, H, W, t.device)])
     if _ones_scope is not None:
         _ones_scope[id(t)] = (t, u1)
     return u1
