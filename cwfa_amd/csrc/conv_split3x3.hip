@@ -264,7 +264,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     };
 
     // ---- weight slices by LDS-DMA: WSL / 1024 wave instructions per slice, a quarter per wave
-    constexpr int NPC = WSL / 1024;                   // 1 KB pieces per slice (12 / 24 / 48), dealt round-robin over the 8 waves
+    // 1 KB pieces per slice (12 / 24 / 48), dealt round-robin over the 8 waves; plain-bf16 mode reads only the leading piece plane of a
+    // slice ([piece][k group][CT][8]: its first third), so only that is fetched
+    constexpr int NPC = (SIX ? WSL : WSL / 3) / 1024;
     const int64_t wtile = (int64_t)ct * p.nsteps * WSL;
     const char* wbase = reinterpret_cast<const char*>(p.wp) + wtile;
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(wbase)), 0, p.nsteps * WSL, 0x00020000);

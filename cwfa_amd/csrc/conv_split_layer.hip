@@ -210,6 +210,12 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wp), 0, p.nprob * NSLK * WSL, 0x00020000);
     // `wb`: byte offset of the problem's packed image (scalar)
     auto dma_w = [&](int slice, int slot, int wb) {
+        if constexpr (!SIX) {                        // plain bf16: only the leading piece plane (the first 4 KB) of a slice is read
+            if (wave < 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + OFF_W + slot * WSL + wave * 1024), 16, (unsigned)tid * 16u,
+                                                         wb + slice * WSL, 0, 0);
+            return;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + OFF_W + slot * WSL + wave * 1024), 16, (unsigned)tid * 16u,
                                                  wb + slice * WSL, 0, 0);
         char* d2 = lds + (wave < 4 ? OFF_W + slot * WSL + 8192 + wave * 1024 : OFF_DUMP + (wave - 4) * 1024);
