@@ -773,6 +773,9 @@ __device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4&
     }
 }
 
+#ifndef CH_BLOCK
+#define CH_BLOCK 256     // (tuning) threads per block of chain_rows4_kernel: a block covers CH_BLOCK * 4 pixels = whole image rows
+#endif
 #ifndef CH_WAVES
 #define CH_WAVES 0       // (tuning) minimum waves per SIMD asked of the register allocator (0: none)
 #endif
@@ -781,9 +784,9 @@ __device__ __forceinline__ void stage_st4(const cwfa_affine_stage& st, const f4&
 // 1536 x 2^k blocks of the 6 / 12 / 24 / 48-channel levels at 512 x 512 fill in whole rounds)
 template <bool INV, int NS = CWFA_CHAIN_MAX>
 #if CH_WAVES
-__global__ __launch_bounds__(256, CH_WAVES) void chain_rows4_kernel(
+__global__ __launch_bounds__(CH_BLOCK, CH_WAVES) void chain_rows4_kernel(
 #else
-__global__ __launch_bounds__(256) void chain_rows4_kernel(
+__global__ __launch_bounds__(CH_BLOCK) void chain_rows4_kernel(
 #endif
 const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
                                                           cwfa_chain ch, const int64_t* __restrict__ final_perm, int C, int H, int W,
@@ -793,7 +796,7 @@ const float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
     // !INV: a0 = x in [2C], a1 = low out [C], a2 = z out [C]
     extern __shared__ float rows[];          // [2][row of the block][W]: exchange buffers of the travelling values (column gathers)
     __shared__ double red[16];
-    const int tpr = W >> 2, RB = 256 / tpr;
+    const int tpr = W >> 2, RB = CH_BLOCK / tpr;
 #if CH_SCALAR
     // a wave holds ONE image row when a row takes a multiple of 64 threads: the row index (and every table entry read with it)
     // is then wave-uniform and goes through the scalar unit
@@ -1046,7 +1049,7 @@ static bool chain_rows_ok(const cwfa_chain* ch, int C, int H, int W, int B, size
 // 16-byte form usable?  W = 4 * (a divisor of 256), every row base and batch stride on a 16-byte boundary
 static bool chain_rows4_ok(const cwfa_chain* ch, int C, int H, int W, int B, size_t* lds, const void* p0, const void* p1,
                            const void* p2, int64_t bs0, int64_t bs1, int64_t bs2) {
-    if (W < 64 || (W & 3) || (W >> 2) > 256 || 256 % (W >> 2) != 0 || C > 65535 || B > 65535) return false;
+    if (W < 64 || (W & 3) || (W >> 2) > CH_BLOCK || CH_BLOCK % (W >> 2) != 0 || C > 65535 || B > 65535) return false;
     if (!cwfa_aligned16(p0) || !cwfa_aligned16(p1) || (p2 && !cwfa_aligned16(p2)) || (bs0 & 3) || (bs1 & 3) || (p2 && (bs2 & 3))) return false;
     for (int k = 0; k < ch->n_stages; ++k) {
         const cwfa_affine_stage& st = ch->stage[k];
@@ -1054,7 +1057,7 @@ static bool chain_rows4_ok(const cwfa_chain* ch, int C, int H, int W, int B, siz
     }
     bool col = false;
     for (int k = 0; k < ch->n_stages; ++k) col = col || (ch->stage[k].perm && ch->stage[k].perm_axis == 3);
-    *lds = col ? (size_t)2 * 1024 * sizeof(float) : 0;      // two exchange rows per block row, only for column gathers
+    *lds = col ? (size_t)2 * CH_BLOCK * 4 * sizeof(float) : 0;      // two exchange rows per block row, only for column gathers
     return *lds <= 64 * 1024;
 }
 
@@ -1080,12 +1083,12 @@ extern "C" int cwfa_chain_inv_f32(const float* z, const float* low, float* x, co
     if (B == 0 || n == 0) return CWFA_OK;
     size_t lds;
     if (chain_rows4_ok(ch, C, H, W, B, &lds, low, x, z, low_bs, x_bs, z_bs)) {
-        const int RB = 1024 / W;
+        const int RB = CH_BLOCK * 4 / W;
         if (ch->n_stages <= 6)
-            hipLaunchKernelGGL((chain_rows4_kernel<true, 6>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
+            hipLaunchKernelGGL((chain_rows4_kernel<true, 6>), dim3((H + RB - 1) / RB, C, B), dim3(CH_BLOCK), lds, (hipStream_t)stream, low, x,
                                const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
         else
-            hipLaunchKernelGGL((chain_rows4_kernel<true, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, low, x,
+            hipLaunchKernelGGL((chain_rows4_kernel<true, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(CH_BLOCK), lds, (hipStream_t)stream, low, x,
                                const_cast<float*>(z), *ch, (const int64_t*)nullptr, C, H, W, low_bs, x_bs, z_bs, logdet, (double*)nullptr);
         CWFA_LAUNCH_CHECK("cwfa_chain_inv_f32");
         return CWFA_OK;
@@ -1114,12 +1117,12 @@ extern "C" int cwfa_chain_fwd_f32(const float* x, float* low, float* z, const cw
     if (B == 0 || n == 0) return CWFA_OK;
     size_t lds;
     if (chain_rows4_ok(ch, C, H, W, B, &lds, x, low, z, x_bs, low_bs, z_bs)) {
-        const int RB = 1024 / W;
+        const int RB = CH_BLOCK * 4 / W;
         if (ch->n_stages <= 6)
-            hipLaunchKernelGGL((chain_rows4_kernel<false, 6>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
+            hipLaunchKernelGGL((chain_rows4_kernel<false, 6>), dim3((H + RB - 1) / RB, C, B), dim3(CH_BLOCK), lds, (hipStream_t)stream, x, low, z,
                                *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
         else
-            hipLaunchKernelGGL((chain_rows4_kernel<false, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(256), lds, (hipStream_t)stream, x, low, z,
+            hipLaunchKernelGGL((chain_rows4_kernel<false, CWFA_CHAIN_MAX>), dim3((H + RB - 1) / RB, C, B), dim3(CH_BLOCK), lds, (hipStream_t)stream, x, low, z,
                                *ch, final_perm, C, H, W, x_bs, low_bs, z_bs, logdet, sumsq);
         CWFA_LAUNCH_CHECK("cwfa_chain_fwd_f32");
         return CWFA_OK;
