@@ -576,7 +576,22 @@ def train_experiment(conv_inn, cond_nets, dev, a, steps, ops):
         one()
     torch.cuda.synchronize()
     dt32 = (time.perf_counter() - t0) / steps
+    # ... and the same iteration as the reference writes it (modules as autograd nodes, loss with torch operators, full_loss.backward():
+    # what `cwfa_amd.install()` gives an unmodified CWFA.py), split precision
+    ops.set_precision("split_bf16")
+    auto = lambda: training.train_iteration_autograd(conv_inn, cond_nets, gt, views, means)     # noqa: E731
+    auto(); auto()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        auto()
+    torch.cuda.synchronize()
+    dta = (time.perf_counter() - t0) / steps
+    for m in list(conv_inn) + list(cond_nets):
+        for p_ in m.parameters():
+            p_.grad = None
     return {"value": B / dt, "unit": "volumes/s", "ms_per_step": 1e3 * dt, "steps": steps, "fp32_kernels_ms_per_step": 1e3 * dt32,
+            "through_autograd_ms_per_step": 1e3 * dta,
             "full_loss_per_pyramid_step": [float(v) for v in res["losses"]], "trainable_parameters": n_par,
             "note": "LRNN + 4 flow steps + condition nets, forward with tape + backward; forward, data gradients and 3x3 weight gradients in "
                     "split-bf16 arithmetic (fp32-equivalent), 1x1 / 1x7 weight gradients and the Conv3d backward on the fp32 kernels; gradients pinned to the "

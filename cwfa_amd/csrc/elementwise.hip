@@ -1003,10 +1003,11 @@ __global__ __launch_bounds__(256) void chain_inv_bwd_kernel(const float* __restr
         }
         const int64_t pix = (int64_t)p.h * W + p.w;
         const float x0 = xhat[b * xhat_bs + (int64_t)(2 * p.c) * HW + pix], x1 = xhat[b * xhat_bs + (int64_t)(2 * p.c + 1) * HW + pix];
-        const float d0 = x0 - gt[b * gt_bs + (int64_t)(2 * p.c) * HW + pix], d1 = x1 - gt[b * gt_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+        const float q0 = gt[b * gt_bs + (int64_t)(2 * p.c) * HW + pix], q1 = gt[b * gt_bs + (int64_t)(2 * p.c + 1) * HW + pix];
+        const float d0 = x0 - q0, d1 = x1 - q1;
         float v = (x0 - x1) * CWFA_INV_SQRT2_F, g;
-        if (loss_kind == 0) {                 // `gt` IS the upstream gradient dL/dxhat (autograd)
-            const float u0 = x0 - d0, u1 = x1 - d1;
+        if (loss_kind == 0) {                 // `gt` IS the upstream gradient dL/dxhat (autograd): taken as loaded (NOT as x - (x - gt):
+            const float u0 = q0, u1 = q1;    // that rounds a gradient of 1e-7 to a multiple of ulp(x) ~ 6e-8 -- round 3's first version)
             g = gscale * ((u0 - u1) * CWFA_INV_SQRT2_F);
             if (glow_out) glow_out[b * n + (int64_t)p.c * HW + pix] = gscale * ((u0 + u1) * CWFA_INV_SQRT2_F);
         } else if (loss_kind == 2) {

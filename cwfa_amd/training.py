@@ -588,6 +588,54 @@ def lrnn_step_backward(encoder, views, mean_vol, gt, loss_func="L2", group=None)
     return loss, out
 
 
+def train_iteration_autograd(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache, cond_weight=0.40984, optimizers=None):
+    """The same iteration written the way the reference writes it (CWFA.py:865-1027): forward through the modules, the loss with
+    torch operators, ``full_loss.backward()`` -- i.e. what a user of ``cwfa_amd.install()`` runs without touching CWFA.py; the
+    modules are autograd nodes (cwfa_amd/autograd.py).  z = 0 (the reference's default temperature), L2 losses, the nets in the
+    modes the caller left them in.  ``optimizers``: optional list (index = pyramid step) of torch optimisers stepped after each
+    backward.  Returns {"losses": [...], "volume": finest reconstruction}."""
+    import torch.nn.functional as F
+    from . import CWFA
+    S = len(conv_inn) + 1
+    gt_cache = [gt_volume]
+    with torch.no_grad():
+        for _ in range(S - 1):
+            y = ops.haar1d(gt_cache[-1], False)
+            gt_cache.append(y[:, :y.shape[1] // 2].contiguous())
+    for m in list(conv_inn) + list(cond_nets):
+        for p in m.parameters():
+            p.grad = None
+
+    def step_opt(n):
+        opt = None if optimizers is None else optimizers[n]
+        for o in (opt if isinstance(opt, (tuple, list)) else (opt,)):
+            if o is not None:
+                o.step()
+                o.zero_grad(set_to_none=True)
+
+    losses = [None] * S
+    with torch.enable_grad():
+        up = cond_nets[S - 1](cond_input, mean_vols_cache[S - 2])[-1]                # CWFA.py:880-886
+        loss = F.mse_loss(gt_cache[S - 1], up)                                       # CWFA.py:936-950
+        loss.backward()
+        losses[S - 1] = loss.detach()
+        step_opt(S - 1)
+        up = up.detach()                                                             # CWFA.py:1015
+        for n in range(S - 2, -1, -1):
+            g = conv_inn[n]
+            cond = [cond_nets[n](cond_input)[-1].float(), mean_vols_cache[n]]        # CWFA.py:893-899
+            z = CWFA.sample_z_truncated((up.shape[0],) + tuple(g.global_out_shapes[0]), device=up.device, temperature=0)
+            xhat, _ = g([z, up], c=cond, rev=True)                                   # CWFA.py:911
+            full = F.mse_loss(gt_cache[n], xhat) * cond_weight                       # CWFA.py:952-959
+            Z, ld = g(gt_cache[n], c=cond)                                           # CWFA.py:966
+            full = full + (0.5 * torch.norm(Z[0]) ** 2 - ld.mean()) / xhat.numel() * (1 - cond_weight)      # CWFA.py:970-987
+            full.backward()                                                          # CWFA.py:1002-1006
+            losses[n] = full.detach()
+            step_opt(n)
+            up = xhat.detach()
+    return {"losses": losses, "volume": up}
+
+
 def train_iteration(conv_inn, cond_nets, gt_volume, cond_input, mean_vols_cache, optimizers=None, lr=None, cond_weight=0.40984,
                     loss_func_reg="L2", loss_func_first_step="L2", z_sampler=None, use_mean_branch=True, group=None,
                     views_noise_std=0.0, cond_dropout=False):

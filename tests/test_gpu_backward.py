@@ -598,3 +598,62 @@ def test_full_size_training_iteration_reduces_the_loss():
     assert all(np.isfinite(h).all() for h in hist), hist
     for n in range(5):
         assert hist[-1][n] < hist[0][n], (n, hist)
+
+
+def test_full_size_iteration_through_autograd_equals_the_manual_path():
+    """training.train_iteration_autograd -- the iteration as the reference writes it (modules as autograd nodes, loss with torch
+    operators, full_loss.backward(), CWFA.py:865-1027) -- at 512x512x96 against training.train_iteration (the manual backward pinned
+    to the reference's gradients by the g13-g15 fixtures): the same per-step losses, the same reconstruction and the same gradients
+    (no optimiser step on either side), in split precision."""
+    from cwfa_amd import CWFA, ops, training
+    import numpy as np
+    torch.manual_seed(0)
+    np.random.seed(0)
+    conv_inn, cond_nets = CWFA.build_networks(96, 512, 5, with_lrnn=True, device="cuda")
+    enc = cond_nets[-1]
+    enc.net.deconv[1].drop_out = 0                       # the stochastic layers off: two runs must see the same function
+    for cn in enc.net.conv3d:
+        cn.drop_prob = 0.0
+    gen = torch.Generator().manual_seed(33)
+    gt = torch.randn(1, 96, 512, 512, generator=gen).cuda()
+    views = torch.randn(1, 29, 512, 512, generator=gen).cuda()
+    means = [(0.1 * torch.randn(1, 96 // 2 ** (n + 1), 512, 512, generator=gen)).cuda() for n in range(4)]
+    mods = list(conv_inn) + list(cond_nets)
+
+    class Keep:                                          # an "optimiser" that only snapshots the step's gradients
+        def __init__(self, ms):
+            self.ps, self.grads = [p for m in ms for p in m.parameters() if p.requires_grad], None
+
+        def step(self):
+            self.grads = [None if p.grad is None else p.grad.clone() for p in self.ps]
+
+        def zero_grad(self, set_to_none=True):
+            for p in self.ps:
+                p.grad = None
+
+    def keepers():
+        return [Keep([cond_nets[n]] if n == 4 else [conv_inn[n], cond_nets[n]]) for n in range(5)]
+
+    ops.set_precision("split_bf16")
+    try:
+        bn_state = {k: v.clone() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k}
+        ka = keepers()
+        a = training.train_iteration_autograd(conv_inn, cond_nets, gt, views, means, optimizers=ka)
+        enc.load_state_dict(bn_state, strict=False)      # (the LRNN's BatchNorm buffers moved: same starting point for the second run)
+        km = keepers()
+        m = training.train_iteration(conv_inn, cond_nets, gt, views, means, optimizers=km)
+    finally:
+        ops.set_precision("fp32")
+    for n in range(5):
+        assert abs(float(a["losses"][n]) - float(m["losses"][n])) <= 2e-5 * abs(float(m["losses"][n])), (n, a["losses"], m["losses"])
+    assert_close(a["volume"], m["volume"], 1e-5, "finest reconstruction")
+    for n in range(5):
+        names = [k for m_ in ([cond_nets[n]] if n == 4 else [conv_inn[n], cond_nets[n]]) for k, p in m_.named_parameters() if p.requires_grad]
+        worst = (0.0, "")
+        for k, ga, gm in zip(names, ka[n].grads, km[n].grads):
+            assert (ga is None) == (gm is None), k
+            if ga is not None and float(gm.abs().max()) > 0:
+                d = float((ga - gm).abs().max()) / float(gm.abs().max())
+                if d > worst[0]:
+                    worst = (d, k + " max|g| = %.3e" % float(gm.abs().max()))
+        assert worst[0] <= 2e-5, (n, worst)

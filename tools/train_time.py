@@ -21,27 +21,7 @@ means = [(0.1 * torch.randn(1, D // 2 ** (n + 1), S, S, generator=gen)).to(dev) 
 
 def reference_style():
     """One iteration as run_CWFA does it: forward through the modules, loss with torch ops, full_loss.backward()."""
-    gt_cache = [gt]
-    with torch.no_grad():
-        for _ in range(4):
-            y = ops.haar1d(gt_cache[-1], False)
-            gt_cache.append(y[:, :y.shape[1] // 2].contiguous())
-    for m in list(conv_inn) + list(cond_nets):
-        for p in m.parameters():
-            p.grad = None
-    up = cond_nets[4](views, means[3])[-1]
-    F.mse_loss(gt_cache[4], up).backward()
-    up = up.detach()
-    for n in range(3, -1, -1):
-        cond = [cond_nets[n](views)[-1].float(), means[n]]
-        z = CWFA.sample_z_truncated((1,) + tuple(conv_inn[n].global_out_shapes[0]), device=dev, temperature=0)
-        xhat, _ = conv_inn[n]([z, up], c=cond, rev=True)
-        full = F.mse_loss(gt_cache[n], xhat) * 0.40984
-        Z, ld = conv_inn[n](gt_cache[n], c=cond)
-        full = full + (0.5 * torch.norm(Z[0]) ** 2 - ld.mean()) / xhat.numel() * (1 - 0.40984)
-        full.backward()
-        up = xhat.detach()
-    return float(full)
+    return float(training.train_iteration_autograd(conv_inn, cond_nets, gt, views, means)["losses"][0])
 
 
 def timeit(fn, n=3):
