@@ -31,6 +31,15 @@ def _need_gpu():
     torch.cuda.synchronize()
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """This file is the parity suite of the INFERENCE path (fused step plans, epilogue couplings, merged launches): grad mode off, as
+    the reference's evaluation code runs it (CWFA.py:134 `torch.no_grad()`).  With grad mode on the same modules run as autograd nodes --
+    that path has its own suites (test_gpu_autograd.py, test_gpu_backward.py)."""
+    with torch.no_grad():
+        yield
+
+
 def names(prefix):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(f"{GOLDEN}/{prefix}*.npz"))
 
