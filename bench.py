@@ -128,11 +128,13 @@ class ConvEvents:
         """family -> [ms, launches, flops, {shape: launches}]"""
         tot = {}
         for key, e0, e1 in self.rows:
-            t = tot.setdefault(family(key), [0.0, 0, 0.0, {}])
-            t[0] += e0.elapsed_time(e1)
+            t = tot.setdefault(family(key), [0.0, 0, 0.0, {}, {}])
+            ms = e0.elapsed_time(e1)
+            t[0] += ms
             t[1] += 1
             t[2] += conv_flops(key)
             t[3][key] = t[3].get(key, 0) + 1
+            t[4][key] = t[4].get(key, 0.0) + ms            # per-shape time (roofline_of: per_shape)
         return tot
 
 
@@ -157,7 +159,7 @@ def conv_bytes(key):
     return 4.0 * (cin * (2 if key[7] else 1) + cout) * H * W * B
 
 
-def roofline_of(fam, t_ms, n, flops, shapes, products, share=None, all_conv_ms=None):
+def roofline_of(fam, t_ms, n, flops, shapes, products, share=None, all_conv_ms=None, shape_ms=None):
     """Roofline object of one conv kernel family.  `algorithmic_tflops` = direct-convolution FLOPs (2*Cout*Cin*taps*H*W
     per launch) / summed HIP-event time; `achieved` = the matrix-core FLOPs the kernel ISSUES for
     them (algorithmic x issued factor) / the same time, against the dense peak of the pipe it runs on: `frac` <= 1."""
@@ -174,6 +176,10 @@ def roofline_of(fam, t_ms, n, flops, shapes, products, share=None, all_conv_ms=N
                     for k, c in sorted(shapes.items(), key=lambda kv: -kv[1])][:6],
          "flops_per_launch": flops / n, "algorithmic_bytes_per_launch": sum(conv_bytes(k) * c for k, c in shapes.items()) / n,
          "avg_launch_ms": t_ms / n, "launches_timed": n}
+    if shape_ms:                             # the family's shapes one by one (a family mixes e.g. full layers and composed first layers)
+        r["per_shape"] = [{"cin": k[1], "cout": k[2], "H": k[3], "form": k[6], "launches": shapes[k], "avg_launch_ms": shape_ms[k] / shapes[k],
+                           "frac": conv_flops(k) * shapes[k] / (shape_ms[k] * 1e-3) / 1e12 * factor / peak}
+                          for k in sorted(shape_ms, key=lambda kk: -shape_ms[kk])][:6]
     if share is not None:
         r["share_of_conv_time"], r["all_conv_ms_per_step"] = share, all_conv_ms
     return r
@@ -361,7 +367,7 @@ def main():
 
     res = None
     if rank == 0:
-        t_dom, n_dom, f_dom, shapes = sink.totals()[dom]
+        t_dom, n_dom, f_dom, shapes, shape_ms = sink.totals()[dom]
         baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
         dtype = {"split": "f32 (storage, accumulation, wavelets, couplings); convolution products on the bf16 matrix cores from an "
                           "exact three-way bf16 split of both fp32 operands, six products per fp32 product: fp32-equivalent; "
@@ -385,7 +391,7 @@ def main():
                                    f"batch {B}/GPU, random-init weights (BASELINE.json configs[2])",
                        "precision": a.precision,
                        "parallelism": f"replicated x{world} (independent volumes per GPU, no collective)"},
-            "roofline": roofline_of(dom, t_dom, n_dom, f_dom, shapes, products, tot[dom][0] / all_conv_ms, all_conv_ms),
+            "roofline": roofline_of(dom, t_dom, n_dom, f_dom, shapes, products, tot[dom][0] / all_conv_ms, all_conv_ms, shape_ms),
             "reference_readme": {"volumes_per_s": 6.25, "note": "README.md:29, unstated CUDA GPU, fp16 autocast; not "
                                  "this fp32 metric, hence vs_baseline is null"},
         }
@@ -396,8 +402,8 @@ def main():
                 step()
             torch.cuda.synchronize()
             ops.conv_event_sink = None
-            t2, n2, f2, sh2 = sink2.totals()[ranked[1]]
-            res["roofline_second"] = roofline_of(ranked[1], t2, n2, f2, sh2, products, tot[ranked[1]][0] / all_conv_ms)
+            t2, n2, f2, sh2, sm2 = sink2.totals()[ranked[1]]
+            res["roofline_second"] = roofline_of(ranked[1], t2, n2, f2, sh2, products, tot[ranked[1]][0] / all_conv_ms, shape_ms=sm2)
             res["roofline_second"]["traffic"], _ = pmc_traffic(ranked[1], a)
         res["roofline_dwt"] = dwt_roofline(ops, step, a, dev)
         if fwd is not None:
@@ -460,8 +466,8 @@ def mode_roofline(ops, step, mode):
             step()
         torch.cuda.synchronize()
         ops.conv_event_sink = None
-        t, n, f, sh = sink.totals()[dom]
-        return roofline_of(dom, t, n, f, sh, 1 if mode == "bf16" else SPLIT_PRODUCTS, tot[dom][0] / all_ms, all_ms)
+        t, n, f, sh, sm = sink.totals()[dom]
+        return roofline_of(dom, t, n, f, sh, 1 if mode == "bf16" else SPLIT_PRODUCTS, tot[dom][0] / all_ms, all_ms, sm)
     finally:
         ops.conv_event_sink = None
         SPLIT_SIX = six
