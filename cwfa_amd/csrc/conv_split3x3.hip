@@ -70,6 +70,7 @@ struct SParams {
     const void* wp;
     float* y;
     int B, Cin, H, W, Cout, nchunks, nsteps, tiles_x, ntiles, ctiles, xcd_map;
+    int nrun;                 // steps that are executed: nsteps, minus the trailing steps of an all-zero odd chunk (3x3 with an odd chunk count)
     int64_t x_bs, y_bs;
     cwfa_conv_opts o;
     cwfa_couple cp;             // EPI_COUPLE only
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(SParams p) {
     // ONE step as the body of a rolled loop (the accumulators are loop-carried values: unrolling the nine steps of a period
     // makes the register allocator split their live ranges and keep copies); P = position in the 9-step period
     int sl = 0, P = 0, ce = 0;                           // ring slot of this step's slice; period position; even chunk of the period
-    for (int step = 0; step < p.nsteps; ++step) {
+    for (int step = 0; step < p.nrun; ++step) {
         const int co = ce + 1;                            // odd chunk (past the end: all zeros, costs only time)
         // units of this step: even chunk taps (2P, 2P+1) for P < 4; (tap 8 | odd tap 0) at P = 4; odd taps (2P-9, 2P-8) after
         // (7x7: 49 taps, the same pairing with a 49-step period)
@@ -732,6 +733,7 @@ extern "C" int cwfa_conv3x3_split_couple_f32(const float* x, const void* w_packe
     p.cp = *cp;
     p.nchunks = (Cin + 15) / 16;
     p.nsteps = nsteps_of(Cin);
+    p.nrun = p.nsteps - ((p.nchunks & 1) ? 4 : 0);
     p.tiles_x = (W + TC - 1) / TC;
     CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(cp->n + 64) * H * W * 4 < (1ll << 31), CWFA_E_SHAPE,
                  "cwfa_conv3x3_split_couple_f32: one sample's input / active half must stay below 2 GiB");
@@ -798,6 +800,9 @@ extern "C" int cwfa_conv3x3_split_f32(const float* x, const void* w_packed, floa
                  "cwfa_conv3x3_split_f32: PReLU without prelu_alpha");
     p.nchunks = (Cin + 15) / 16;
     p.nsteps = nsteps_of(Cin);
+    // an odd number of 16-channel chunks: the last period's odd chunk is all zeros and the steps that pair ONLY its taps (positions 5 .. 8 of
+    // the period: odd taps (1,2) (3,4) (5,6) (7,8)) add nothing -- not run (a 6 -> 256 convolution: five steps instead of nine)
+    p.nrun = p.nsteps - ((p.nchunks & 1) ? 4 : 0);
     p.tiles_x = (W + TC - 1) / TC;
     const int mpw = mpw_of(Cout);
     CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(Cout + 64 * mpw) * H * W * 4 < (1ll << 31) &&
@@ -871,6 +876,7 @@ extern "C" int cwfa_conv7x7_split_f32(const float* x, const void* w_packed, floa
                  CWFA_E_INVAL, "cwfa_conv7x7_split_f32: bias-only epilogue, no load-side prologue, NCHW maps");
     p.nchunks = (Cin + 15) / 16;
     p.nsteps = nsteps_of(Cin, 49);
+    p.nrun = p.nsteps;
     p.tiles_x = (W + TC - 1) / TC;
     CWFA_REQUIRE((int64_t)(Cin + 64) * H * W * 4 < (1ll << 31) && (int64_t)(Cout + 64) * H * W * 4 < (1ll << 31), CWFA_E_SHAPE,
                  "cwfa_conv7x7_split_f32: one sample's input / output must stay below 2 GiB");
