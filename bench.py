@@ -140,8 +140,8 @@ class ConvEvents:
 
 def conv_flops(key):
     ks, cin, cout, H, W, B = key[:6]
-    if ks == "L" and key[6].startswith("layer1x"):  # ... with the first map as a third k step: + 64 x 32
-        return 2.0 * cout * (cin * 9 + cout + cin) * H * W * B
+    if ks == "L" and key[6].startswith("layer1x"):  # ... with the first map as a third k step: + 64 x 32 (cin = 16: the short form)
+        return 2.0 * cout * (cin * 9 + cout + 32) * H * W * B
     if ks == "L" and key[6].startswith("layer1"):   # first layer in composed form: 3x3 over the (padded) 32 input channels + the 64 x 64 1x1
         return 2.0 * cout * (cin * 9 + cout) * H * W * B
     taps = 10 if ks == "L" else ks * ks          # "L": fused 3x3 + 1x1 sub-network layer (9 + 1 taps)

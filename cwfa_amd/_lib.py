@@ -116,7 +116,7 @@ SIGNATURES = {
     "cwfa_subnet_layer_split_f32": (i, [p, p, p, p, p, i, i, i, i64, i64, i, p]),
     "cwfa_subnet_layer_split_tape_f32": (i, [p, p, p, p, p, p, i, i, i, i64, i64, i64, p]),
     "cwfa_subnet_layer_first_packed_bytes": (i64, []),
-    "cwfa_subnet_layer_first_pack_f32": (i, [p, p, p, p, p]),
+    "cwfa_subnet_layer_first_pack_f32": (i, [p, p, p, i, p, p]),
     "cwfa_subnet_layer_first_f32": (i, [p, p, p, p, p, p, i, i, i, i, i64, i64, i64, i, p]),
     "cwfa_extract_views_f32": (i, [p, p, p, i, i, i, i, i, i, f, f, i64, p]),
 }

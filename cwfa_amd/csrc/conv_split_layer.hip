@@ -124,11 +124,16 @@ __host__ __device__ constexpr int unit_off(int u) {
 // [h ; u | 1], with u's values at the tile's pixels loaded straight into the B-fragment layout (8 channels of a pixel per lane, L2-hot:
 // the staging just read the same tile) and W0' = [W0 | b0 | 0] as one more slice of the packed image, read from memory (12 KB,
 // cache-resident; the LDS is full): the sub-network's first 1x1 launch and its 64-channel map disappear.
-template <bool SIX, bool INB, bool OUTB, int NPER = 2, bool TAPE = false, bool XF = false>
+// SHORT (with XF): u has <= 16 channels (the coarse steps: 13 / 7 + the ones channel), i.e. ONE 16-channel chunk -- the odd chunk is all
+// zeros and the four steps that pair only its taps add nothing: five conv steps per tile.  The odd LDS buffer is zeroed once (its tap 0
+// rides in step 4 beside tap 8 against zero weights); the next tile's chunk is requested during steps 0 .. 2 and written into the even
+// buffer behind step 4's barrier, at the head of the 1x1 phase (whose closing barrier publishes it).
+template <bool SIX, bool INB, bool OUTB, int NPER = 2, bool TAPE = false, bool XF = false, bool SHORT = false>
 __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     static_assert(!TAPE || (!INB && !OUTB && NPER == 2), "tape form: NCHW maps, full layer");
     static_assert(!XF || (NPER == 1 && !INB && !TAPE), "fused first map: the composed first-layer form");
-    constexpr int NSTEP = 9 * NPER, NSLK = NSTEP + 2 + (XF ? 1 : 0);     // conv steps per tile; weight slices per problem
+    static_assert(!SHORT || XF, "short form: the composed first layer with its fused first map");
+    constexpr int NSTEP = SHORT ? 5 : 9 * NPER, NSLK = NSTEP + 2 + (XF ? 1 : 0);     // conv steps per tile; weight slices per problem
     constexpr bool UIN = NPER == 1;                      // the 3x3 input is p.u (NCHW), not p.x
     constexpr bool INS = INB && !UIN;                    // layout of the STAGED tensor
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -266,7 +271,16 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
     const float* xs_cur = UIN ? p.u + (int64_t)tb * p.u_bs : p.x + (int64_t)tb * p.x_bs;
     entry_offsets(true, row0, col0, fo_c);
     sfor<3>([&](auto kc) { load_entry(xa[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 0); });
-    sfor<3>([&](auto kc) { load_entry(xb[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 1); });
+    if constexpr (!SHORT) {
+        sfor<3>([&](auto kc) { load_entry(xb[decltype(kc)::value], xs_cur, fo_c[decltype(kc)::value], 1); });
+    } else {                                     // the odd buffer: zeros, once
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (fin[k] && (k < 2 || stage2)) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(lds + XB + edst[k] + q * XPB) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
     int wb_cur = problem_of(tb) * (NSLK * WSL);
     dma_w(0, 0, wb_cur);
     sfor<3>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], 0); });
@@ -303,13 +317,17 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
             constexpr int S = decltype(sc)::value, P = S % 9, PER = S / 9;
             constexpr bool LASTP = PER == NPER - 1;            // the last period stages the NEXT tile's chunks 0 and 1
             const int s1 = next_slot(cs), s2 = next_slot(s1);
-            constexpr bool LOADS = (P >= 2 && P <= 4) || P >= 6;
+            constexpr bool LOADS = SHORT ? P <= 2 : ((P >= 2 && P <= 4) || P >= 6);
             // the slice DMA(s), then this step's staging loads (which may stay in flight across the barrier) -- issued from
             // INSIDE the MFMA stream, after the first m-tile: in a burst right behind the barrier all eight waves stood in
             // their issue cost (~100 cycles per DMA instruction) at once with the matrix pipe idle
             auto issue_memory = [&]() {
                 if constexpr (S == 0) dma_w(1, s1, wb_cur);     // (late by one step: the 1x1 phase counts as one)
                 dma_w(S + 2, s2, wb_cur);
+                if constexpr (SHORT) {                          // the one chunk of the next tile
+                    if constexpr (P <= 2) load_entry(xa[P], xs_next, fo_n[P], 0);
+                    return;
+                }
                 if constexpr (P >= 2 && P <= 4) {               // even chunk 2*PER+2 (last period: chunk 0 of the next tile)
                     constexpr int k = P - 2;
                     if constexpr (!LASTP) load_entry(xa[k], xs_cur, fo_c[k], 2 * PER + 2);
@@ -347,8 +365,8 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
                 if (mt == 0) {
                     issue_memory();
                     FENCE();
-                    if constexpr (P <= 2) store_entry(ic<P>{}, xb[P], 1);
-                    if constexpr (P >= 5 && P <= 7) store_entry(ic<P - 5>{}, xa[P - 5], 0);
+                    if constexpr (!SHORT && P <= 2) store_entry(ic<P>{}, xb[P], 1);
+                    if constexpr (!SHORT && P >= 5 && P <= 7) store_entry(ic<P - 5>{}, xa[P - 5], 0);
                     FENCE();
                 }
             }
@@ -366,6 +384,9 @@ __global__ __launch_bounds__(512, 1) void split_layer_kernel(LParams p) {
         });
 
         // ------------------------------------------------------------------------------------------ 1x1 + epilogue
+        if constexpr (SHORT) {      // the next tile's chunk into the even buffer: its last reader (step 4) is behind a barrier
+            sfor<3>([&](auto kc) { store_entry(kc, xa[decltype(kc)::value], 0); });
+        }
         {
             const int sw0 = cs, sw1 = next_slot(cs), sn0 = next_slot(sw1);         // W1 slices, next tile's slice 0
             dma_w(0, sn0, wb_next);
@@ -599,11 +620,12 @@ extern "C" int cwfa_subnet_layer_split_pack_f32(const float* w3, const float* w1
 
 extern "C" int64_t cwfa_subnet_layer_first_packed_bytes(void) { return (int64_t)12 * WSL; }
 
-extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, void* packed, void* stream) {
+extern "C" int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, int short_form, void* packed, void* stream) {
     CWFA_REQUIRE(w3c && w1 && packed, CWFA_E_INVAL, "cwfa_subnet_layer_first_pack_f32: null pointer");
     CWFA_REQUIRE(cwfa_aligned16(packed), CWFA_E_ALIGN, "cwfa_subnet_layer_first_pack_f32: packed image must be 16-byte aligned");
+    CWFA_REQUIRE(!short_form || w0c, CWFA_E_INVAL, "cwfa_subnet_layer_first_pack_f32: the short form is a form of the fused first map (w0c)");
     hipLaunchKernelGGL(split_layer_pack_kernel, dim3((12 * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3c, w1,
-                       reinterpret_cast<uint4*>(packed), 9, 32, w0c);
+                       reinterpret_cast<uint4*>(packed), short_form ? 5 : 9, 32, w0c);
     CWFA_LAUNCH_CHECK("cwfa_subnet_layer_first_pack_f32");
     return CWFA_OK;
 }
@@ -634,7 +656,11 @@ extern "C" int cwfa_subnet_layer_first_f32(const float* u, const float* x, const
 
 static int layer_launch(const float* x, const void* packed, const float* b3, const float* b1, float* y, int B, int H, int W, int64_t x_bs,
                         int64_t y_bs, int layout, int nprob, int spp, void* stream, const float* u, int64_t u_bs, int u_ch, float* hid, int64_t hid_bs) {
-    CWFA_REQUIRE(layout >= 0 && layout <= 3, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..3", layout);
+    CWFA_REQUIRE(layout >= 0 && layout <= 7, CWFA_E_INVAL, "cwfa_subnet_layer_split_f32: layout %d not in 0..7", layout);
+    const bool shortf = (layout & 4) != 0;                  // (first-layer form only) the packed image is the SHORT one
+    layout &= 3;
+    CWFA_REQUIRE(!shortf || (u && !x && u_ch >= 1 && u_ch <= 16), CWFA_E_INVAL,
+                 "cwfa_subnet_layer_first_f32: the short form needs x == NULL and u_ch <= 16 (got %d)", u_ch);
     CWFA_REQUIRE(!(layout & 1) || cwfa_aligned16(x), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input must be 16-byte aligned");
     CWFA_REQUIRE(!(layout & 2) || cwfa_aligned16(y), CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked output must be 16-byte aligned");
     CWFA_REQUIRE(!(layout & 1) || (x_bs & 3) == 0, CWFA_E_ALIGN, "cwfa_subnet_layer_split_f32: blocked input batch stride must be a multiple of 4");
@@ -684,9 +710,11 @@ static int layer_launch(const float* x, const void* packed, const float* b3, con
     static const kern_t tape_kerns[2] = {&split_layer_kernel<false, false, false, 2, true>, &split_layer_kernel<true, false, false, 2, true>};
     static const kern_t xf_kerns[2][2] = {{&split_layer_kernel<false, false, false, 1, false, true>, &split_layer_kernel<false, false, true, 1, false, true>},
                                           {&split_layer_kernel<true, false, false, 1, false, true>, &split_layer_kernel<true, false, true, 1, false, true>}};
-    const int first = fused_x ? 3 : u != nullptr ? 1 : hid != nullptr ? 2 : 0;
-    kern_t kern = first == 3 ? xf_kerns[six][layout >> 1] : first == 2 ? tape_kerns[six] : kerns[first][six][layout];
-    static bool attr_set_all[4][2][4] = {};
+    static const kern_t xs_kerns[2][2] = {{&split_layer_kernel<false, false, false, 1, false, true, true>, &split_layer_kernel<false, false, true, 1, false, true, true>},
+                                          {&split_layer_kernel<true, false, false, 1, false, true, true>, &split_layer_kernel<true, false, true, 1, false, true, true>}};
+    const int first = shortf ? 4 : fused_x ? 3 : u != nullptr ? 1 : hid != nullptr ? 2 : 0;
+    kern_t kern = first == 4 ? xs_kerns[six][layout >> 1] : first == 3 ? xf_kerns[six][layout >> 1] : first == 2 ? tape_kerns[six] : kerns[first][six][layout];
+    static bool attr_set_all[5][2][4] = {};
     bool& attr_done = attr_set_all[first][six][layout];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -265,7 +265,7 @@ class wavelet_flow_subnetwork(nn.Module):
 
     def _first3(self, conv0, conv3, conv1):
         srcs = [conv0.weight, conv3.weight, conv1.weight] + ([conv0.bias] if conv0.bias is not None else [])
-        key = tuple((t._version, t.data_ptr()) for t in srcs) + (ops.pack_epoch(),)
+        key = tuple((t._version, t.data_ptr()) for t in srcs) + (ops.pack_epoch(), bool(ops.FIRST_LAYER_FUSED_X))
         hit = self._panels.get(("f", id(conv3)))
         if hit is None or hit[0] != key:
             hit = self._panels[("f", id(conv3))] = (key, ops.pack_first_layer_weight(conv0.weight, conv0.bias, conv3.weight, conv1.weight))

@@ -366,7 +366,7 @@ def chain_bwd(z, stages, grads, final_perm=None, gscale=0.0, ldscale=0.0, gz=Non
 class PackedConv:
     """Kernel-layout image of one filter bank (built once per weight version on the device)."""
     __slots__ = ("packed", "cout", "cin", "ks", "transposed", "version", "src_ptr", "split", "epoch", "version1", "src_ptr1", "cat_c1",
-                 "cat_from")
+                 "cat_from", "short")
 
     def __init__(self, packed, cout, cin, ks, transposed, version, src_ptr, split=False):
         self.packed, self.cout, self.cin, self.ks = packed, cout, cin, ks
@@ -681,7 +681,7 @@ FIRST_LAYER_COMPOSED = True   # (tuning / ablation) False: the first layer of a 
 FIRST_LAYER_FUSED_X = True      # ... and its residual conv1x1(u) + b0 formed inside that launch (no first 1x1 launch, no first map in memory)
 
 
-def pack_first_layer_weight(w0, b0, w3, w1):
+def pack_first_layer_weight(w0, b0, w3, w1, short=None):
     """The composed bank of a sub-network's FIRST layer (cwfa_subnet_layer_first_f32): conv3x3(conv1x1(u, w0) + b0, w3) =
     conv3x3(u | 1, w3c) with w3c[o][i][tap] = sum_m w3[o][m][tap] [w0 | b0][m][i] (formed in float64, rounded once), zero-padded to
     32 input channels; w0 [64,cin,1,1] with cin <= 31, b0 [64] or None, w3 [64,64,3,3], w1 [64,64,1,1]."""
@@ -697,8 +697,13 @@ def pack_first_layer_weight(w0, b0, w3, w1):
     w0c = torch.zeros((64, 32), dtype=torch.float32, device=w0.device)          # [W0 | b0 | 0]: the first map as a third k step of the 1x1 phase
     w0c[:, :cin + 1] = w0p.to(torch.float32)
     packed = torch.empty(L.cwfa_subnet_layer_first_packed_bytes(), dtype=torch.uint8, device=w0.device)
-    check(L.cwfa_subnet_layer_first_pack_f32(_p(w3c), _p(w1), _p(w0c), _p(packed), _stream()), "subnet_layer_first_pack")
+    # short form (u has one 16-channel chunk: five conv steps instead of nine) -- only launched with x = None (subnet_layer_first)
+    short = (FIRST_LAYER_FUSED_X and cin + 1 <= 16) if short is None else bool(short)
+    if short and cin + 1 > 16:
+        raise ValueError("pack_first_layer_weight: the short form needs cin + 1 <= 16")
+    check(L.cwfa_subnet_layer_first_pack_f32(_p(w3c), _p(w1), _p(w0c), int(short), _p(packed), _stream()), "subnet_layer_first_pack")
     pc = PackedConv(packed, 64, cin + 1, 3, False, w3._version, w3.data_ptr(), split=True)
+    pc.short = short
     pc.version1, pc.src_ptr1 = w1._version, w1.data_ptr()
     return pc
 
@@ -717,15 +722,18 @@ def subnet_layer_first(u1, x, pc, b3, b1, layout=0):
     if (x is not None and tuple(x.shape) != (B, 64, H, W)) or Cu != pc.cin:
         raise ValueError(f"subnet_layer_first: u1 {tuple(u1.shape)} / x {None if x is None else tuple(x.shape)} do not match the composed "
                          f"bank ({pc.cin} inputs)")
+    short = bool(getattr(pc, "short", False))
+    if short and x is not None:
+        raise ValueError("subnet_layer_first: a short-form image (pack_first_layer_weight(short=True)) forms its first map itself: x must be None")
     out = torch.empty((B, 64, H, W), dtype=torch.float32, device=u1.device)
     rec = conv_event_sink
     if rec is not None:
-        key = ("L", 32, 64, H, W, B, "layer1+split" if x is not None else "layer1x+split", False)
+        key = ("L", 16 if short else 32, 64, H, W, B, "layer1+split" if x is not None else "layer1x+split", False)
         if rec.want(key):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
     check(L.cwfa_subnet_layer_first_f32(_p(u1), _p(x), _p(pc.packed), _p(_dev(b3)), _p(_dev(b1)), _p(out), B, Cu, H, W, ubs, xbs,
-                                        64 * H * W, int(layout), _stream()), "subnet_layer_first")
+                                        64 * H * W, int(layout) | (4 if short else 0), _stream()), "subnet_layer_first")
     if rec is not None and rec.want(key):
         e1.record()
         rec.add(key, e0, e1)

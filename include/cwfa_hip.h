@@ -372,9 +372,11 @@ int cwfa_subnet_layer_split_f32(const float* x, const void* packed, const float*
  * zero in unused input channels; w1 [64,64,1,1]; w0c nullable): cwfa_subnet_layer_first_packed_bytes() bytes.
  * With w0c = [W0 | b0 | 0] ([64,32], the 1x1 bank over u's channels and the ones channel) in the packed image and x == NULL the
  * residual is not read either: the layer's 1x1 phase takes it as a third k step, [W1 | W0c] . [h ; u], from u's values at the tile's
- * pixels -- the sub-network's first 1x1 launch and its 64-channel map never exist. */
+ * pixels -- the sub-network's first 1x1 launch and its 64-channel map never exist.  SHORT form (pack with short_form = 1, launch
+ * with layout bit 2 = 4, x == NULL, u_ch <= 16 = one 16-channel chunk): five instead of nine convolution steps per tile -- the steps
+ * that pair only taps of the all-zero second chunk are not run. */
 int64_t cwfa_subnet_layer_first_packed_bytes(void);
-int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, void* packed, void* stream);
+int cwfa_subnet_layer_first_pack_f32(const float* w3c, const float* w1, const float* w0c, int short_form, void* packed, void* stream);
 int cwfa_subnet_layer_first_f32(const float* u, const float* x, const void* packed, const float* b3, const float* b1, float* y, int B,
                                 int u_ch, int H, int W, int64_t u_bs, int64_t x_bs, int64_t y_bs, int layout, void* stream);
 /* Tape form (training forward, SURVEY.md 8f row 1 / CWFA.py:966-1006): the same launch also writes the hidden map

@@ -1615,7 +1615,9 @@ def test_first_layer_composed_form_is_fp32_accurate(cfg):
     ref = F.elu(F.conv2d(F.elu(F.conv2d(x64, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + x64)
     ops.set_precision("split_bf16")
     try:
-        pc = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda())
+        pc = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda(), short=False)     # nine conv steps, either residual form
+        pcx = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda())                 # the default: short where cin + 1 <= 16
+        assert pcx.short == (cin + 1 <= 16)
         x = ops.conv2d(u.cuda(), ops.pack_conv_weight(w0.cuda()), bias=b0.cuda())
         u1 = ops.with_ones(u.cuda())
         assert u1.shape[1] == cin + 1 and float(u1[:, -1].min()) == 1.0
@@ -1628,6 +1630,14 @@ def test_first_layer_composed_form_is_fp32_accurate(cfg):
         assert_close(yx, ref, 5e-6, "composed first layer, fused first map")
         yxb = ops.subnet_layer_first(u1, None, pc, b3.cuda(), b1.cuda(), layout=2)
         assert torch.equal(_from_blocked(yxb), yx)
+        # ... and in its short form where u is one 16-channel chunk (five conv steps): the same sums in the same order
+        ys = ops.subnet_layer_first(u1, None, pcx, b3.cuda(), b1.cuda())
+        assert_close(ys, ref, 5e-6, "composed first layer, fused first map, default image")
+        if pcx.short:
+            assert torch.equal(ys, yx)
+            assert torch.equal(_from_blocked(ops.subnet_layer_first(u1, None, pcx, b3.cuda(), b1.cuda(), layout=2)), ys)
+            with pytest.raises(ValueError):
+                ops.subnet_layer_first(u1, x, pcx, b3.cuda(), b1.cuda())                  # a short image forms its first map itself
         # the plain layer on the same maps: the same function up to the rounding of x between the two convolutions
         y2 = ops.subnet_layer(x, ops.pack_split_layer_weight(w3.cuda(), w1.cuda()), b3.cuda(), None, b1.cuda())
         assert_close(y2, y, 5e-6, "composed vs two-step")

@@ -23,9 +23,11 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     w1, b1 = torch.randn(64, 64, 1, 1) / 8, torch.randn(64) * 0.1
     x64 = F.conv2d(u.double(), w0.double(), b0.double())
     ref = F.elu(F.conv2d(F.elu(F.conv2d(x64, w3.double(), b3.double(), padding=1)), w1.double(), b1.double()) + x64)
-    pc = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda())
+    pc = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda(), short=False)
+    pcx = ops.pack_first_layer_weight(w0.cuda(), b0.cuda(), w3.cuda(), w1.cuda())          # short form where cin + 1 <= 16
     u1 = ops.with_ones(u.cuda())
     note("first layer, fused map", rel(ops.subnet_layer_first(u1, None, pc, b3.cuda(), b1.cuda()), ref), 6e-6, (B, cin, H, W))
+    note("first layer, fused map, default image", rel(ops.subnet_layer_first(u1, None, pcx, b3.cuda(), b1.cuda(), layout=random.choice([0, 2]) * 0), ref), 6e-6, (B, cin, H, W))
     x = ops.conv2d(u.cuda(), ops.pack_conv_weight(w0.cuda()), bias=b0.cuda())
     note("first layer, map from memory", rel(ops.subnet_layer_first(u1, x, pc, b3.cuda(), b1.cuda()), ref), 6e-6, (B, cin, H, W))
     # tape form
