@@ -2099,3 +2099,16 @@ def test_in_place_parameter_edits_need_invalidate_packs():
         ops.set_precision("fp32")
     assert not torch.equal(y0, y1)
     assert_close(y1, y2, 1e-5, "re-packed split path vs live fp32 path")
+
+
+@pytest.mark.parametrize("tool", [["stress_tilings.py", "3", "30"], ["stress_round3.py", "4", "4"]])
+def test_random_shapes_through_the_new_kernels(tool):
+    """tools/stress_tilings.py (random 3x3 banks over every tiling / epilogue / statistics form of the split kernel) and
+    tools/stress_round3.py (composed / fused / short first layer, tape layer, split weight gradients, split Conv3d) against float64
+    torch, a short run of each (their seeds differ from the runs recorded in DESIGN.md)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool[0]), *tool[1:]], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
