@@ -1597,7 +1597,8 @@ def test_split_layer_channel_blocked_layouts(shape):
         ops.set_precision("fp32")
 
 
-@pytest.mark.parametrize("cfg", [(1, 6, 40, 70), (2, 12, 33, 50), (1, 24, 64, 64), (1, 31, 17, 33), (1, 1, 16, 32)])
+# ((6, *, 160, 160): 300 tiles on 256 persistent workgroups -- the next-tile staging of every form runs)
+@pytest.mark.parametrize("cfg", [(1, 6, 40, 70), (2, 12, 33, 50), (1, 24, 64, 64), (1, 31, 17, 33), (1, 1, 16, 32), (6, 13, 160, 160), (6, 25, 160, 160)])
 def test_first_layer_composed_form_is_fp32_accurate(cfg):
     """cwfa_subnet_layer_first_f32: the first layer of a sub-network with its 3x3 composed with the 1x1 in front
     (networks.py:621-631,641-665: conv3x3(conv1x1(u) + b0) = conv3x3'(u | 1), K = 9 x 32) against float64 torch evaluating the two
@@ -1813,7 +1814,7 @@ def test_sharded_nll_two_ranks_on_the_gpu_path():
         assert abs(nll - float(ref)) <= 1e-6 * abs(float(ref)), (nll, float(ref))
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96), (3, 16, 32), (1, 5, 3), (2, 130, 200)])
+@pytest.mark.parametrize("shape", [(1, 32, 32), (2, 17, 45), (1, 70, 96), (3, 16, 32), (1, 5, 3), (2, 130, 200), (6, 160, 160)])
 def test_split_fused_layer_is_fp32_accurate(shape):
     """The fused sub-network layer with both convolutions on the split-bf16 core (persistent kernel, several tiles per
     workgroup at the larger shapes, ragged borders): same reference, same tolerance as the fp32 MFMA layer."""
