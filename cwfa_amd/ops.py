@@ -395,7 +395,9 @@ def pack_conv_weight(w, transposed=False, direct=False):
         packed = torch.empty(L.cwfa_conv_split_packed_bytes(cout, cin, ks), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv_split_pack_f32(_p(w), _p(packed), cout, cin, ks, int(transposed), _stream()), "conv_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
-    if not direct and _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT and (cout > 32 or (cout <= SPLIT_3X3_NARROW_MAX and cin >= 29)):
+    # (bf16 mode: one product per multiply-add -- there the 32-channel tiling beats the fp32 Winograd kernel for 17 .. 32 outputs too)
+    narrow_max = 32 if _plain_bf16 else SPLIT_3X3_NARROW_MAX
+    if not direct and _split_bf16 >= 2 and ks == 3 and cout >= SPLIT_3X3_MIN_COUT and (cout > 32 or (cout <= narrow_max and cin >= 29)):
         packed = torch.empty(L.cwfa_conv3x3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
         check(L.cwfa_conv3x3_split_pack_f32(_p(w), _p(packed), cout, cin, _stream()), "conv3x3_split_pack")
         return PackedConv(packed, cout, cin, ks, transposed, w._version, w.data_ptr(), split=True)
@@ -1257,6 +1259,7 @@ def extract_views(image, coords_yx, subimage_shape, mean=0.0, std=1.0):
 
 
 _split_bf16 = 0
+_plain_bf16 = False      # set_precision("bf16"): the split kernels with ONE product (BASELINE.json configs[4])
 _pack_epoch = 0
 
 
@@ -1299,6 +1302,8 @@ def set_precision(mode):
     permutations, the Conv3d of the condition nets and the remaining small convolutions stay fp32."""
     if mode not in ("fp32", "split_bf16", "bf16"):
         raise ValueError(f"set_precision: unknown mode {mode!r}")
+    global _plain_bf16
+    _plain_bf16 = mode == "bf16"
     set_option("split_products", 1 if mode == "bf16" else 6)
     set_option("split_bf16", 0 if mode == "fp32" else 2)
     set_option("wgrad_split", 0 if mode == "fp32" else 1)        # training: 3x3 weight gradients in the same arithmetic (csrc/conv_bwd.hip)
