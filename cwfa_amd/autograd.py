@@ -110,9 +110,12 @@ class _SubnetFn(Function):
 REUSE_SUBNET_NODES = True     # see subnet()
 
 
+_subnet_memo = weakref.WeakKeyDictionary()      # sub-network module -> (key, weakref of its output, weakref of its input); NOT an attribute of
+#                                                 the module: weak references would make `torch.save(module)` / pickle fail
+
+
 def _forget(net):
-    if getattr(net, "_cwfa_ag_memo", None) is not None:
-        object.__setattr__(net, "_cwfa_ag_memo", None)
+    _subnet_memo.pop(net, None)
 
 
 def subnet(net, u, conv_in, conv_out):
@@ -122,21 +125,21 @@ def subnet(net, u, conv_in, conv_out):
     inverse pass of the reconstruction term (CWFA.py:911) and in the forward pass of the NLL term (CWFA.py:966) -- and lets
     autograd add the two gradient contributions.  A sub-network is a deterministic function of (input, parameters), so the second
     call returns the FIRST call's output tensor: one forward, and -- the node being shared -- one backward with the summed gradient.
-    The memo lives on the module, is keyed by the input tensor object / version and every parameter's version, holds its tensors
+    The memo (a WeakKeyDictionary over the modules) is keyed by the input tensor object / version and every parameter's version, holds its tensors
     weakly and is dropped as soon as the node's backward has run."""
     convs = [conv_in, net.block2[0], net.block2[2], net.block4[0], net.block4[2], net.block6[0], net.block6[2], conv_out]
     params = _params_of([c.weight for c in convs] + [c.bias for c in convs])
     key = None
     if REUSE_SUBNET_NODES:
         key = (id(u), u._version, id(conv_in), id(conv_out), ops.pack_epoch(), ops._split_bf16) + tuple((id(p), p._version) for p in params)
-        hit = getattr(net, "_cwfa_ag_memo", None)
+        hit = _subnet_memo.get(net)
         if hit is not None and hit[0] == key:
             out, src = hit[1](), hit[2]()
             if out is not None and src is u:
                 return out
     out = _SubnetFn.apply(net, conv_in, conv_out, u, *params)
     if key is not None:
-        object.__setattr__(net, "_cwfa_ag_memo", (key, weakref.ref(out), weakref.ref(u)))
+        _subnet_memo[net] = (key, weakref.ref(out), weakref.ref(u))
     return out
 
 
